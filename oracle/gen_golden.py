@@ -1,0 +1,302 @@
+"""Generate tests/golden/*.npz by running the REFERENCE in the build container.
+
+Run:  python oracle/gen_golden.py          (needs /root/reference; CPU only)
+
+Every fixture stores the exact inputs next to the reference's outputs, so the
+tests need neither the reference nor this script at run time.  Only data is
+written: arrays of inputs, cores, Gram matrices, right-hand sides, steps,
+losses.  No reference source text goes into the repository.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from load_reference import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_default_dtype(torch.float64)
+ref = load_reference()
+layers, bregman, network = ref["layers"], ref["bregman"], ref["network"]
+
+
+def npz(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def make_loss(kind):
+    if kind == "square":
+        return bregman.SquareBregFunction()
+    if kind == "mse":
+        return bregman.AutogradLoss()
+    if kind == "xe":
+        return bregman.XEAutogradBregman(w=1.0)
+    raise ValueError(kind)
+
+
+def make_data(S, N, p, C, kind, seed, list_input=True):
+    g = torch.Generator().manual_seed(seed)
+    if list_input:
+        x = [torch.rand(S, p, generator=g) * 2 - 1 for _ in range(N)]
+    else:
+        x = torch.rand(S, p, generator=g) * 2 - 1
+    if kind == "xe":
+        lab = torch.randint(0, C + 1, (S,), generator=g)
+        y = torch.nn.functional.one_hot(lab, C + 1).to(torch.float64)
+    else:
+        y = torch.randn(S, C, generator=g)
+    return x, y
+
+
+def cores_of(layer):
+    return [n.tensor.detach().clone() for n in layer.tensor_network.main_nodes]
+
+
+def save_x(d, x):
+    if isinstance(x, list):
+        for i, t in enumerate(x):
+            d[f"x{i}"] = t
+        d["x_is_list"] = 1
+    else:
+        d["x"] = x
+        d["x_is_list"] = 0
+
+
+# ---------------------------------------------------------------- 1. core update
+def gen_core_update(tag, N, p, r, C, S, kind, constrict, list_input, seed):
+    layer = layers.TensorTrainLayer(N, r, p, output_shape=C, constrict_bond=constrict, seed=seed)
+    tn = layer.tensor_network
+    x, y = make_data(S, N, p, C, kind, seed + 100, list_input)
+    d = {"N": N, "p": p, "r": r, "C": C, "S": S, "seed": seed, "constrict": int(constrict), "y": y,
+         "loss_kind": np.array(kind)}
+    save_x(d, x)
+    for i, c in enumerate(cores_of(layer)):
+        d[f"core{i}"] = c
+    loss_fn = make_loss(kind)
+    y_pred = tn.forward(x, to_tensor=True)
+    loss, g, H = loss_fn.forward(y_pred, y)
+    d["y_pred"], d["loss"], d["g"], d["H"] = y_pred, loss, g, H
+    v_gen = torch.Generator().manual_seed(seed + 7)
+    for k, node in enumerate(tn.train_nodes):
+        A, b = tn.get_A_b(node, g, H)
+        d[f"A{k}"], d[f"b{k}"] = A, b
+        d[f"b_only{k}"] = tn.get_b(node, g)
+        # matrix-free product through get_J exactly as lanczos_swipe does (network.py:781-789)
+        v = torch.randn(node.tensor.shape, generator=v_gen)
+        pj = tn.get_J(node, g)
+        coeff = torch.einsum(f"{pj['einsum']},{pj['node_ein']},{pj['dd_loss_ein']}->{pj['coeff_ein']}", pj['J'].tensor, v, H)
+        Av = torch.einsum(f"{pj['einsum']},{pj['d_loss_ein']}->{pj['node_ein']}", pj['J'].tensor, coeff)
+        d[f"v{k}"], d[f"Av{k}"] = v, Av
+        for method in ["exact", "ridge_exact", "ridge_cholesky", "cholesky"]:
+            for ei, eps in enumerate([0.0, 1e-3, 1.0]):
+                if eps == 0.0 and method in ("exact", "cholesky", "ridge_cholesky"):
+                    continue  # rank-deficient without ridge at these sizes
+                if method in ("exact", "cholesky") and ei > 1:
+                    continue
+                try:
+                    step = tn.solve_system(node, A, b, method=method, eps=eps)
+                    d[f"step_{method}_{ei}_{k}"] = step
+                except torch.linalg.LinAlgError:
+                    d[f"fail_{method}_{ei}_{k}"] = 1
+        d[f"step_gradient_{k}"] = tn.solve_system(node, A, b, method="gradient")
+    d["eps_values"] = np.array([0.0, 1e-3, 1.0])
+    npz(f"tt_core_update_{tag}", **d)
+
+
+# ---------------------------------------------------------------- 2. swipe traces
+def gen_swipe(tag, N, p, r, C, S, kind, bs, seed, **kw):
+    layer = layers.TensorTrainLayer(N, r, p, output_shape=C, constrict_bond=True, seed=seed)
+    tn = layer.tensor_network
+    x, y = make_data(S, N, p, C, kind, seed + 100, True)
+    d = {"N": N, "p": p, "r": r, "C": C, "S": S, "seed": seed, "bs": bs, "y": y, "loss_kind": np.array(kind)}
+    save_x(d, x)
+    for i, c in enumerate(cores_of(layer)):
+        d[f"core{i}"] = c
+    for k_, v_ in kw.items():
+        d["kw_" + k_] = np.array(v_)
+    losses, visits, snaps = [], [], []
+
+    def loss_cb(NS, node, loss):
+        losses.append(loss)
+        visits.append((NS, tn.main_nodes.index(node)))
+
+    def block_cb(NS, node):
+        snaps.append([n.tensor.detach().clone() for n in tn.main_nodes])
+
+    if kw.get("orthonormalize", False):
+        tn.orthonormalize_left()
+        for i, c in enumerate(cores_of(layer)):
+            d[f"core_after_init_qr{i}"] = c
+    ok = tn.accumulating_swipe(x, y, make_loss(kind), batch_size=bs, loss_callback=loss_cb,
+                               block_callback=block_cb, **kw)
+    d["ok"] = int(ok)
+    d["losses"] = np.array(losses)
+    d["visits"] = np.array(visits)
+    for u, snap in enumerate(snaps):
+        for i, c in enumerate(snap):
+            d[f"u{u}_core{i}"] = c
+    d["num_updates"] = len(snaps)
+    npz(f"swipe_trace_{tag}", **d)
+
+
+# ---------------------------------------------------------------- 3. estimators
+def gen_tnml(tag, S, F, r, degree, basis, seed, **kw):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(-1, 1, (S, F))
+    y = np.sin(X).sum(1, keepdims=True) + 0.01 * rng.randn(S, 1)
+    est = ref["tnml"].TNMLRegressor(r=r, output_dim=1, seed=42, device="cpu", basis=basis, degree=degree, **kw)
+    est.fit(X, y)
+    Xt = rng.uniform(-1, 1, (64, F))
+    d = {"X": X, "y": y, "Xt": Xt, "pred": est.predict(Xt), "r": r, "degree": degree, "basis": np.array(basis)}
+    for k_, v_ in kw.items():
+        d["kw_" + k_] = np.array(v_)
+    vh = est._early_stopper.val_history
+    d["val_history"] = np.array([vh[k] for k in sorted(vh)])
+    for i, n in enumerate(est._model.tensor_network.main_nodes):
+        d[f"core{i}"] = n.tensor
+    npz(f"tnml_fit_{tag}", **d)
+
+
+def gen_ttreg(tag, seed, task, **kw):
+    rng = np.random.RandomState(seed)
+    if task == "regression":
+        S, F = 300, 4
+        X = rng.uniform(-1, 1, (S, F))
+        y = (X ** 2).sum(1, keepdims=True) + X[:, :1] * X[:, 1:2] + 0.01 * rng.randn(S, 1)
+        bf = None
+    else:
+        from sklearn.datasets import load_iris
+        data = load_iris()
+        X = data.data
+        X = (X - X.mean(0)) / X.std(0)
+        yl = data.target
+        y = np.eye(3)[yl]
+        bf = bregman.XEAutogradBregman(w=1.0)
+    est = ref["tensor_train"].TensorTrainRegressor(device="cpu", task=task, bf=bf, **kw)
+    est.fit(X, y)
+    d = {"X": X, "y": y, "pred": est.predict(X[:50]), "task": np.array(task)}
+    for k_, v_ in kw.items():
+        d["kw_" + k_] = np.array(v_)
+    vh = est._early_stopper.val_history
+    d["val_history"] = np.array([vh[k] for k in sorted(vh)])
+    for i, n in enumerate(est._model.tensor_network.main_nodes):
+        d[f"core{i}"] = n.tensor
+    npz(f"ttreg_fit_{tag}", **d)
+
+
+# ---------------------------------------------------------------- 4/5. Krylov swipes
+def gen_lanczos(tag, N, p, r, C, S, kind, bs, seed, num_swipes, max_iter, tol):
+    layer = layers.TensorTrainLayer(N, r, p, output_shape=C, constrict_bond=True, seed=seed)
+    tn = layer.tensor_network
+    x, y = make_data(S, N, p, C, kind, seed + 100, True)
+    d = {"N": N, "p": p, "r": r, "C": C, "S": S, "seed": seed, "bs": bs, "y": y, "loss_kind": np.array(kind),
+         "num_swipes": num_swipes, "max_iter": max_iter, "tol": tol, "torch_seed": seed + 5}
+    save_x(d, x)
+    for i, c in enumerate(cores_of(layer)):
+        d[f"core{i}"] = c
+    # x0 draws: one randn_like(b_rhs) per visited node, nothing else uses the generator
+    torch.manual_seed(seed + 5)
+    order = []
+    for NS in range(num_swipes):
+        order += list(range(N)) if NS % 2 == 0 else list(reversed(range(N)))
+    for u, k in enumerate(order):
+        d[f"x0_{u}"] = torch.randn_like(tn.main_nodes[k].tensor)
+    snaps, losses = [], []
+    torch.manual_seed(seed + 5)
+    ok = tn.lanczos_swipe(x, y, make_loss(kind), batch_size=bs, num_swipes=num_swipes, max_iter=max_iter, tol=tol,
+                          block_callback=lambda NS, node: snaps.append([n.tensor.detach().clone() for n in tn.main_nodes]),
+                          loss_callback=lambda l: losses.append(l))
+    d["ok"] = int(ok)
+    d["losses"] = np.array(losses)
+    d["order"] = np.array(order)
+    for u, snap in enumerate(snaps):
+        for i, c in enumerate(snap):
+            d[f"u{u}_core{i}"] = c
+    d["num_updates"] = len(snaps)
+    npz(f"lanczos_{tag}", **d)
+
+
+def gen_scipy(tag, solver_name, N, p, r, C, S, kind, bs, seed, num_swipes, max_iter, tol):
+    import scipy.sparse.linalg as spla
+    solver = getattr(spla, solver_name)
+    layer = layers.TensorTrainLayer(N, r, p, output_shape=C, constrict_bond=True, seed=seed)
+    tn = layer.tensor_network
+    x, y = make_data(S, N, p, C, kind, seed + 100, True)
+    d = {"N": N, "p": p, "r": r, "C": C, "S": S, "seed": seed, "bs": bs, "y": y, "loss_kind": np.array(kind),
+         "num_swipes": num_swipes, "max_iter": max_iter, "tol": tol, "solver": np.array(solver_name)}
+    save_x(d, x)
+    for i, c in enumerate(cores_of(layer)):
+        d[f"core{i}"] = c
+    snaps, losses = [], []
+    ok = tn.scipy_swipe(x, y, make_loss(kind), solver, batch_size=bs, num_swipes=num_swipes, max_iter=max_iter, tol=tol,
+                        block_callback=lambda NS, node: snaps.append([n.tensor.detach().clone() for n in tn.main_nodes]),
+                        loss_callback=lambda l: losses.append(l))
+    d["ok"] = int(ok)
+    d["losses"] = np.array(losses)
+    for u, snap in enumerate(snaps):
+        for i, c in enumerate(snap):
+            d[f"u{u}_core{i}"] = c
+    d["num_updates"] = len(snaps)
+    npz(f"scipy_{solver_name}_{tag}", **d)
+
+
+# ---------------------------------------------------------------- 8. QR gauge
+def gen_qr(tag, N, p, r, C, seed):
+    layer = layers.TensorTrainLayer(N, r, p, output_shape=C, constrict_bond=True, seed=seed)
+    tn = layer.tensor_network
+    d = {"N": N, "p": p, "r": r, "C": C}
+    for i, c in enumerate(cores_of(layer)):
+        d[f"core{i}"] = c
+    tn.orthonormalize_left()
+    for i, c in enumerate(cores_of(layer)):
+        d[f"left_core{i}"] = c
+    tn.orthonormalize_right()
+    for i, c in enumerate(cores_of(layer)):
+        d[f"leftright_core{i}"] = c
+    npz(f"qr_gauge_{tag}", **d)
+
+
+if __name__ == "__main__":
+    gen_core_update("n4p3r4c1_sq", 4, 3, 4, 1, 96, "square", True, True, 1)
+    gen_core_update("n5p4r6c3_sq", 5, 4, 6, 3, 96, "square", True, True, 2)
+    gen_core_update("n4p3r4c3_mse", 4, 3, 4, 3, 96, "mse", True, True, 3)
+    gen_core_update("n4p5r4c2_xe", 4, 5, 4, 2, 96, "xe", False, False, 4)
+    gen_core_update("n3p5r4c2_xe_iris_shape", 3, 5, 4, 2, 120, "xe", False, False, 5)
+
+    gen_swipe("chol_ortho", 5, 4, 6, 1, 200, "square", 64, 11, num_swipes=2, method="ridge_cholesky", eps=1.0,
+              eps_decay=0.5, orthonormalize=True, direction="l2r")
+    gen_swipe("exact_r2l", 4, 3, 4, 1, 150, "square", 50, 12, num_swipes=2, method="ridge_exact", eps=0.1,
+              eps_decay=0.5, orthonormalize=False, direction="r2l")
+    gen_swipe("skip_second_fullbatch", 4, 3, 4, 2, 128, "mse", -1, 13, num_swipes=3, method="ridge_cholesky", eps=0.5,
+              eps_decay=0.7, skip_second=True)
+    gen_swipe("eps_list_per_node", 4, 3, 4, 1, 128, "square", 48, 14, num_swipes=1, method="ridge_exact",
+              eps=[1.0, 0.5, 0.25, 0.125], eps_per_node=True, lr=0.7)
+    gen_swipe("xe_c2", 4, 5, 4, 2, 160, "xe", 64, 15, num_swipes=2, method="ridge_cholesky", eps=1.0, eps_decay=0.5)
+    gen_swipe("gradient", 4, 3, 4, 1, 128, "square", 64, 16, num_swipes=1, method="gradient", lr=0.01)
+    gen_swipe("adaptive_maxnorm", 4, 3, 4, 1, 128, "square", 64, 17, num_swipes=1, method="ridge_cholesky", eps=1e-3,
+              adaptive_step=True, max_norm=0.8)
+
+    gen_tnml("poly_r6", 400, 5, 6, 3, "polynomial", 0, early_stopping=4, num_swipes=2, batch_size=128)
+    gen_tnml("sincos_r4", 300, 4, 4, 3, "sin-cos", 1, early_stopping=3, num_swipes=2, batch_size=100)
+    gen_ttreg("reg_n3r4", 2, "regression", N=3, r=4, output_dim=1, early_stopping=5, num_swipes=2, batch_size=100)
+    gen_ttreg("iris_n3r4", 3, "classification", N=3, r=4, output_dim=2, early_stopping=8, num_swipes=5,
+              batch_size=512)
+
+    gen_lanczos("n4p3r4c1", 4, 3, 4, 1, 128, "square", 48, 21, 2, 8, 1e-6)
+    gen_lanczos("n4p4r4c2_xe", 4, 4, 4, 2, 128, "xe", 64, 22, 1, 12, 1e-6)
+    gen_scipy("n4p3r4c1", "cg", 4, 3, 4, 1, 128, "square", 48, 23, 2, 15, 1e-6)
+    gen_scipy("n4p3r4c1", "minres", 4, 3, 4, 1, 128, "square", 48, 24, 2, 15, 1e-6)
+
+    gen_qr("n5p4r6c1", 5, 4, 6, 1, 31)
+    gen_qr("n4p3r4c3", 4, 3, 4, 3, 32)
