@@ -1,0 +1,115 @@
+/* ttk.h -- C ABI of the MI355X (gfx950) tensor-train core-update kernels.
+ *
+ * The reference (niccogc/TensorNetworksFork) has no FFI: its hot path is a
+ * chain of torch.einsum / torch.linalg calls inside tensor/network.py.  Each
+ * entry point below replaces one of those call sites; the citation names the
+ * reference lines whose arithmetic it performs.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to dense row-major arrays, 8-byte aligned;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - no entry point allocates: scratch comes in through `ws` (size from the
+ *     matching *_ws_bytes function);
+ *   - return value: 0 ok, negative = rejected argument (nothing was launched).
+ *
+ * Index names: s sample (S), c/d output (C), l/m left bond (rl), p/q physical
+ * (p), r/t right bond (rr), D = rl*p*rr.
+ */
+#ifndef TTK_H
+#define TTK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTK_OK 0
+#define TTK_EINVAL (-1)   /* bad extent / null pointer */
+#define TTK_EWORKSPACE (-2) /* workspace too small */
+#define TTK_ELAUNCH (-3)  /* hipLaunch reported an error */
+
+int ttk_version(void);
+
+/* Left environment step  out[s,c,r] = sum_{l,p} E[s,c,l] core[l,p,r] X[s,p].
+ * E (S,C,rl), X (S,p), core (rl,p,rr), out (S,C,rr).
+ * Replaces the pair of einsums issued by TensorNode.contract_with for one
+ * column of compute_stacks('left') / left_update_stacks
+ * (tensor/network.py:55-71,152-161; tensor/node.py:28-45). */
+int ttk_env_step_left_f64(const double* E, const double* X, const double* core, double* out,
+                          int64_t S, int C, int rl, int p, int rr, void* stream);
+
+/* Right environment step  out[s,l] = sum_{p,r} core[l,p,r] X[s,p] R[s,r].
+ * R (S,rr), X (S,p), core (rl,p,rr), out (S,rl).
+ * compute_stacks('right') / right_update_stacks (tensor/network.py:55-71,163-172). */
+int ttk_env_step_right_f64(const double* R, const double* X, const double* core, double* out,
+                           int64_t S, int rl, int p, int rr, void* stream);
+
+/* Prediction  y[s,c] = sum_r L[s,c,r] R[s,r]; L (S,C,r), R (S,r), y (S,C).
+ * Last contraction of TensorNetwork.forward (tensor/network.py:121-131). */
+int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int C, int r, void* stream);
+
+/* Losses: per-sample value, gradient g (S,C) and Hessian H (S,C,C) w.r.t. the
+ * model output.  kind 0: SquareBregFunction (tensor/bregman.py:9-23,34-52;
+ * loss (S), H all-ones*2 as the reference's (S,C,1) broadcast acts inside
+ * get_A_b, tensor/network.py:188,212); kind 1: AutogradLoss(MSELoss(none))
+ * (bregman.py:266-292; loss (S,C), H = 2 I); kind 2: XEAutogradBregman(w)
+ * (bregman.py:189-216; y is one-hot (S,C+1); loss (S)). */
+int ttk_loss_f64(int kind, double w, const double* y_pred, const double* y, double* loss, double* g,
+                 double* H, int64_t S, int C, void* stream);
+
+/* out[0] = mean over mini-batches of the per-batch mean of v (n_per_sample
+ * values per sample), the quantity accumulating_swipe reports
+ * (tensor/network.py:472-474,493-494). */
+int ttk_batch_mean_f64(const double* v, int64_t S, int n_per_sample, int64_t batch, double* out, void* stream);
+
+/* HL[s,d,l] = sum_c H[s,c,d] L[s,c,l]  (S,C,rl): the Hessian-weighted left
+ * factor of the Gram einsum (tensor/network.py:207,212). */
+int ttk_hess_left_f64(const double* H, const double* L, double* HL, int64_t S, int C, int rl, void* stream);
+
+/* Gram matrix of the local normal equations
+ *   A[(l,p,r),(m,q,t)] = sum_{s,c,d} H[s,c,d] L[s,c,l]X[s,p]R[s,r] L[s,d,m]X[s,q]R[s,t]
+ * (get_A_b, tensor/network.py:174-212, summed over mini-batches as in 463-468).
+ * Computed in symmetry-compressed form into ws, then expanded:
+ *   ttk_gram_f64        -> compressed G in ws  (needs HL from ttk_hess_left_f64)
+ *   ttk_gram_scale_f64  -> scale[0] = mean_i |A_ii| (1 if 0)      (network.py:298-300)
+ *   ttk_gram_expand_f64 -> A_out (D,D) = A / scale[0] + ridge*I   (network.py:301,308,312)
+ *                          (scale == NULL means 1).
+ * sym_left != 0 asserts H[s] symmetric (exploits l<->m symmetry). */
+int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left);
+int ttk_gram_f64(const double* L, const double* HL, const double* X, const double* R,
+                 int64_t S, int C, int rl, int p, int rr, int sym_left,
+                 void* ws, int64_t ws_bytes, void* stream);
+int ttk_gram_scale_f64(const void* ws, int rl, int p, int rr, int sym_left, double* scale, void* stream);
+int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, const double* scale,
+                        double ridge, double* A_out, void* stream);
+
+/* Right-hand side / transposed Jacobian product
+ *   b[l,p,r] = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]
+ * (get_A_b / get_b, tensor/network.py:215,289; second einsum of the matrix-free
+ * product, network.py:789).  b (rl,p,rr). */
+int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr);
+int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b,
+                int64_t S, int C, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream);
+
+/* Jacobian-vector product  u[s,c] = sum_{l,p,r} L[s,c,l] X[s,p] R[s,r] v[l,p,r]
+ * followed by hu[s,d] = sum_c H[s,c,d] u[s,c]  (first einsum of the matrix-free
+ * product, tensor/network.py:788).  tmp (S,C,rr) scratch; hu (S,C). */
+int ttk_jvp_f64(const double* L, const double* X, const double* R, const double* H, const double* v,
+                double* tmp, double* hu, int64_t S, int C, int rl, int p, int rr, void* stream);
+
+/* Right-hand side of the scaled, ridge-shifted system, negated:
+ *   out[i] = -( b[i] / scale[0] + ridge * w[i] )            (network.py:302,309,313,315)
+ * scale == NULL means 1; w == NULL means no shift. */
+int ttk_solve_rhs_f64(const double* b, const double* w, const double* scale, double ridge, double* out,
+                      int64_t D, void* stream);
+
+/* Krylov vector kernels with wavefront-shuffle reductions (lanczos_solver,
+ * tensor/network.py:796-824): out[0] = <x,y>;  y += a[0]*x  (a on device);
+ * Both leave results on the device so that an iteration needs no host sync. */
+int ttk_dot_f64(const double* x, const double* y, double* out, int64_t n, void* stream);
+int ttk_axpy_f64(const double* a, double sign, const double* x, double* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTK_H */

@@ -1,0 +1,214 @@
+"""torch.Tensor front-ends of the C ABI: argument checks, output allocation,
+current-stream plumbing.  No arithmetic happens here."""
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(t, name, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.TTKError(f"{name}: expected a CUDA/HIP tensor (the core-update path has no CPU fallback)")
+    if t.dtype != F64:
+        raise _lib.TTKError(f"{name}: expected float64, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.TTKError(f"{name}: expected a contiguous tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.TTKError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def prep(t):
+    """Contiguous float64 view/copy on the same device (plumbing only)."""
+    if t.dtype != F64:
+        t = t.to(F64)
+    return t.contiguous()
+
+
+def env_step_left(E, X, core):
+    """E (S,C,rl), X (S,p), core (rl,p,rr) -> (S,C,rr)."""
+    S, C, rl = E.shape
+    p, rr = core.shape[1], core.shape[2]
+    out = torch.empty((S, C, rr), dtype=F64, device=E.device)
+    if S == 0:
+        return out
+    rc = _lib.lib().ttk_env_step_left_f64(_chk(E, "E"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
+                                          out.data_ptr(), S, C, rl, p, rr, _stream(E))
+    _lib.check(rc, "ttk_env_step_left_f64")
+    return out
+
+
+def env_step_right(R, X, core):
+    """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl)."""
+    S, rr = R.shape
+    rl, p = core.shape[0], core.shape[1]
+    out = torch.empty((S, rl), dtype=F64, device=R.device)
+    if S == 0:
+        return out
+    rc = _lib.lib().ttk_env_step_right_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
+                                           out.data_ptr(), S, rl, p, rr, _stream(R))
+    _lib.check(rc, "ttk_env_step_right_f64")
+    return out
+
+
+def predict(L, R):
+    """L (S,C,r), R (S,r) -> (S,C)."""
+    S, C, r = L.shape
+    y = torch.empty((S, C), dtype=F64, device=L.device)
+    if S == 0:
+        return y
+    rc = _lib.lib().ttk_predict_f64(_chk(L, "L"), _chk(R, "R", (S, r)), y.data_ptr(), S, C, r, _stream(L))
+    _lib.check(rc, "ttk_predict_f64")
+    return y
+
+
+LOSS_KINDS = {"square": 0, "mse": 1, "xe": 2}
+
+
+def loss(kind, y_pred, y, w=1.0):
+    """-> (loss, g (S,C), H (S,C,C)); loss is (S,) for square/xe and (S,C) for mse."""
+    S, C = y_pred.shape
+    k = LOSS_KINDS[kind]
+    ycols = C + 1 if k == 2 else C
+    lo = torch.empty((S, C) if k == 1 else (S,), dtype=F64, device=y_pred.device)
+    g = torch.empty((S, C), dtype=F64, device=y_pred.device)
+    H = torch.empty((S, C, C), dtype=F64, device=y_pred.device)
+    if S == 0:
+        return lo, g, H
+    rc = _lib.lib().ttk_loss_f64(k, float(w), _chk(y_pred, "y_pred"), _chk(y, "y", (S, ycols)), lo.data_ptr(),
+                                 g.data_ptr(), H.data_ptr(), S, C, _stream(y_pred))
+    _lib.check(rc, "ttk_loss_f64")
+    return lo, g, H
+
+
+def batch_mean(v, batch):
+    """Mean over mini-batches (of `batch` samples) of per-batch means; 0-d device tensor."""
+    S = v.shape[0]
+    nps = v.numel() // S
+    out = torch.empty((), dtype=F64, device=v.device)
+    rc = _lib.lib().ttk_batch_mean_f64(_chk(v, "v"), S, nps, int(batch), out.data_ptr(), _stream(v))
+    _lib.check(rc, "ttk_batch_mean_f64")
+    return out
+
+
+def hess_left(H, L):
+    S, C, rl = L.shape
+    HL = torch.empty_like(L)
+    rc = _lib.lib().ttk_hess_left_f64(_chk(H, "H", (S, C, C)), _chk(L, "L"), HL.data_ptr(), S, C, rl, _stream(L))
+    _lib.check(rc, "ttk_hess_left_f64")
+    return HL
+
+
+class GramWorkspace:
+    """Symmetry-compressed Gram matrix held in a device workspace."""
+
+    def __init__(self, S, C, rl, p, rr, sym, device):
+        self.dims = (int(S), int(C), int(rl), int(p), int(rr), int(bool(sym)))
+        nbytes = _lib.lib().ttk_gram_ws_bytes(*self.dims)
+        if nbytes < 0:
+            raise _lib.TTKError("ttk_gram_ws_bytes: invalid extents")
+        self.nbytes = int(nbytes)
+        self.buf = torch.empty((self.nbytes + 7) // 8, dtype=F64, device=device)
+
+
+def gram(L, HL, X, R, sym=True, ws=None):
+    """Compressed Gram of the local normal equations -> GramWorkspace."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    if ws is None or ws.dims != (S, C, rl, p, rr, int(bool(sym))):
+        ws = GramWorkspace(S, C, rl, p, rr, sym, L.device)
+    rc = _lib.lib().ttk_gram_f64(_chk(L, "L"), _chk(HL, "HL", (S, C, rl)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
+                                 S, C, rl, p, rr, int(bool(sym)), ws.buf.data_ptr(), ws.nbytes, _stream(L))
+    _lib.check(rc, "ttk_gram_f64")
+    return ws
+
+
+def gram_scale(ws):
+    _, _, rl, p, rr, sym = ws.dims
+    scale = torch.empty((), dtype=F64, device=ws.buf.device)
+    rc = _lib.lib().ttk_gram_scale_f64(ws.buf.data_ptr(), rl, p, rr, sym, scale.data_ptr(), _stream(ws.buf))
+    _lib.check(rc, "ttk_gram_scale_f64")
+    return scale
+
+
+def gram_expand(ws, scale=None, ridge=0.0, out=None):
+    """Full (D,D) matrix A/scale + ridge*I."""
+    _, _, rl, p, rr, sym = ws.dims
+    D = rl * p * rr
+    if out is None:
+        out = torch.empty((D, D), dtype=F64, device=ws.buf.device)
+    rc = _lib.lib().ttk_gram_expand_f64(ws.buf.data_ptr(), rl, p, rr, sym,
+                                        None if scale is None else _chk(scale, "scale"), float(ridge),
+                                        _chk(out, "A_out", (D, D)), _stream(ws.buf))
+    _lib.check(rc, "ttk_gram_expand_f64")
+    return out
+
+
+_rhs_ws = {}
+
+
+def rhs(L, X, R, g):
+    """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    nbytes = _lib.lib().ttk_rhs_ws_bytes(S, C, rl, p, rr)
+    if nbytes < 0:
+        raise _lib.TTKError("ttk_rhs_ws_bytes: invalid extents")
+    key = (L.device, int(nbytes))
+    ws = _rhs_ws.get(key)
+    if ws is None:
+        _rhs_ws.clear()
+        ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
+        _rhs_ws[key] = ws
+    b = torch.empty((rl, p, rr), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_rhs_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(g, "g", (S, C)),
+                                b.data_ptr(), S, C, rl, p, rr, ws.data_ptr(), int(nbytes), _stream(L))
+    _lib.check(rc, "ttk_rhs_f64")
+    return b
+
+
+def jvp(L, X, R, H, v):
+    """hu (S,C) = H . (J v) for the local Jacobian J = L (x) X (x) R."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    tmp = torch.empty((S, C, rr), dtype=F64, device=L.device)
+    hu = torch.empty((S, C), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_jvp_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(H, "H", (S, C, C)),
+                                _chk(v, "v", (rl, p, rr)), tmp.data_ptr(), hu.data_ptr(), S, C, rl, p, rr, _stream(L))
+    _lib.check(rc, "ttk_jvp_f64")
+    return hu
+
+
+def matvec(L, X, R, H, v):
+    """(J^T H J) v without forming the Gram matrix."""
+    return rhs(L, X, R, jvp(L, X, R, H, v))
+
+
+def solve_rhs(b, w=None, scale=None, ridge=0.0):
+    """-(b/scale + ridge*w), flattened."""
+    D = b.numel()
+    out = torch.empty((D,), dtype=F64, device=b.device)
+    rc = _lib.lib().ttk_solve_rhs_f64(_chk(b, "b"), None if w is None else _chk(w, "w"),
+                                      None if scale is None else _chk(scale, "scale"), float(ridge), out.data_ptr(), D,
+                                      _stream(b))
+    _lib.check(rc, "ttk_solve_rhs_f64")
+    return out
+
+
+def dot(x, y):
+    out = torch.empty((), dtype=F64, device=x.device)
+    rc = _lib.lib().ttk_dot_f64(_chk(x, "x"), _chk(y, "y"), out.data_ptr(), x.numel(), _stream(x))
+    _lib.check(rc, "ttk_dot_f64")
+    return out
+
+
+def axpy(a, x, y, sign=1.0):
+    """y += sign * a * x with `a` a 0-d device tensor (no host sync)."""
+    rc = _lib.lib().ttk_axpy_f64(_chk(a, "a"), float(sign), _chk(x, "x"), _chk(y, "y"), x.numel(), _stream(x))
+    _lib.check(rc, "ttk_axpy_f64")
+    return y

@@ -1,0 +1,132 @@
+"""HIP kernels (through the C ABI) against the CPU oracle on seeded inputs."""
+import pytest
+import torch
+
+from oracle import tt_oracle as O
+from tests import _golden as G
+
+gpu = pytest.mark.gpu
+TOL = 1e-10  # fp64 kernels vs fp64 oracle, relative Frobenius error
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+
+
+SHAPES = [  # S, C, rl, p, rr
+    (96, 1, 4, 3, 4), (130, 3, 6, 4, 6), (77, 2, 1, 5, 4), (64, 1, 4, 3, 1), (513, 1, 32, 6, 32),
+    (200, 2, 7, 5, 9), (1, 1, 3, 2, 3), (300, 1, 24, 50, 24), (100, 9, 9, 17, 20), (257, 1, 48, 5, 70),
+]
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", SHAPES)
+def test_env_steps(S, C, rl, p, rr):
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    E, X, core, R = _rand((S, C, rl), 1), _rand((S, p), 2), _rand((rl, p, rr), 3), _rand((S, rr), 4)
+    out = ops.env_step_left(E.to(dev), X.to(dev), core.to(dev))
+    assert G.rel_err(out, O.env_left_step(E, core, X)) < TOL
+    out = ops.env_step_right(R.to(dev), X.to(dev), core.to(dev))
+    assert G.rel_err(out, O.env_right_step(R, core, X)) < TOL
+    Lk = _rand((S, C, rr), 5)
+    y = ops.predict(Lk.to(dev), R.to(dev))
+    assert G.rel_err(y, torch.einsum('scr,sr->sc', Lk, R)) < TOL
+
+
+@gpu
+@pytest.mark.parametrize("kind,C", [("square", 1), ("square", 3), ("mse", 1), ("mse", 4), ("xe", 1), ("xe", 2), ("xe", 9)])
+def test_losses(kind, C):
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    S = 333
+    yp = _rand((S, C), 7) * 3
+    if kind == "xe":
+        lab = torch.randint(0, C + 1, (S,), generator=torch.Generator().manual_seed(8))
+        y = torch.nn.functional.one_hot(lab, C + 1).to(torch.float64)
+    else:
+        y = _rand((S, C), 9)
+    lo, g, H = ops.loss(kind, yp.to(dev), y.to(dev), w=1.3 if kind == "xe" else 1.0)
+    kw = {"w": 1.3} if kind == "xe" else {}
+    lo_r, g_r, H_r = O.LOSSES[kind](yp, y, **kw)
+    assert G.rel_err(lo, lo_r) < 1e-12
+    assert G.rel_err(g, g_r) < 1e-12
+    assert G.rel_err(H, H_r) < 1e-12
+    for batch in (50, 333, 1000):
+        m = ops.batch_mean(lo, batch).item()
+        ref = sum(lo_r[b0:b0 + batch].mean().item() for b0 in range(0, S, batch)) / ((S + batch - 1) // batch)
+        assert abs(m - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", SHAPES)
+def test_gram_rhs_matvec(S, C, rl, p, rr):
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    if rl * p * rr > 4000:
+        pytest.skip("dense reference too large for the CPU suite")
+    L, X, R = _rand((S, C, rl), 11), _rand((S, p), 12), _rand((S, rr), 13)
+    g = _rand((S, C), 14)
+    Hh = _rand((S, C, C), 15)
+    Hsym = Hh @ Hh.transpose(1, 2) + 0.1 * torch.eye(C, dtype=torch.float64)
+    for sym, H in ((True, Hsym), (False, Hh)):
+        A_r, b_r = O.local_gram_rhs(L, X, R, g, H)
+        Ld, Xd, Rd, Hd = L.to(dev), X.to(dev), R.to(dev), H.contiguous().to(dev)
+        HL = ops.hess_left(Hd, Ld)
+        ws = ops.gram(Ld, HL, Xd, Rd, sym=sym)
+        A = ops.gram_expand(ws)
+        D = rl * p * rr
+        assert G.rel_err(A, A_r.reshape(D, D)) < TOL, ("gram", sym)
+        scale = ops.gram_scale(ws)
+        sc_r = A_r.reshape(D, D).diag().abs().mean()
+        assert abs(scale.item() - sc_r.item()) <= 1e-12 * sc_r.item()
+        A2 = ops.gram_expand(ws, scale=scale, ridge=0.25)
+        assert G.rel_err(A2, A_r.reshape(D, D) / sc_r + 0.25 * torch.eye(D, dtype=torch.float64)) < TOL
+        b = ops.rhs(Ld, Xd, Rd, g.to(dev))
+        assert G.rel_err(b, b_r) < TOL
+        v = _rand((rl, p, rr), 16)
+        Av = ops.matvec(Ld, Xd, Rd, Hd, v.to(dev))
+        assert G.rel_err(Av, O.local_matvec(L, X, R, H, v)) < TOL, ("matvec", sym)
+        w = _rand((rl, p, rr), 17)
+        sr = ops.solve_rhs(b, w.to(dev), scale, 0.5)
+        assert G.rel_err(sr, -(b_r / sc_r + 0.5 * w).reshape(-1)) < TOL
+
+
+@gpu
+def test_krylov_vector_ops():
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    x, y = _rand((6144,), 21), _rand((6144,), 22)
+    xd, yd = x.to(dev), y.to(dev)
+    d = ops.dot(xd, yd)
+    assert abs(d.item() - (x * y).sum().item()) < 1e-10
+    ops.axpy(d, xd, yd, sign=-1.0)
+    assert G.rel_err(yd, y - (x * y).sum() * x) < 1e-12
+
+
+@gpu
+def test_gram_large_slabbed():
+    """Multi-slab path (S large enough for 8 sample slabs) against linearity: the Gram of
+    the whole set equals the sum of Grams of two halves, and a dense check on a sub-block."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    S, C, rl, p, rr = 20000, 1, 8, 6, 8
+    L, X, R = _rand((S, C, rl), 31), _rand((S, p), 32), _rand((S, rr), 33)
+    H = torch.full((S, 1, 1), 2.0, dtype=torch.float64)
+    A_r, _ = O.local_gram_rhs(L, X, R, torch.zeros(S, 1, dtype=torch.float64), H)
+    Ld, Xd, Rd, Hd = L.to(dev), X.to(dev), R.to(dev), H.to(dev)
+    A = ops.gram_expand(ops.gram(Ld, ops.hess_left(Hd, Ld), Xd, Rd, sym=True))
+    D = rl * p * rr
+    assert G.rel_err(A, A_r.reshape(D, D)) < TOL
+    h = S // 2
+    A1 = ops.gram_expand(ops.gram(Ld[:h].contiguous(), ops.hess_left(Hd[:h].contiguous(), Ld[:h].contiguous()),
+                                  Xd[:h].contiguous(), Rd[:h].contiguous(), sym=True))
+    A2 = ops.gram_expand(ops.gram(Ld[h:].contiguous(), ops.hess_left(Hd[h:].contiguous(), Ld[h:].contiguous()),
+                                  Xd[h:].contiguous(), Rd[h:].contiguous(), sym=True))
+    assert G.rel_err(A1 + A2, A) < 1e-12
