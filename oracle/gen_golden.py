@@ -295,8 +295,8 @@ if __name__ == "__main__":
 
     gen_lanczos("n4p3r4c1", 4, 3, 4, 1, 128, "square", 48, 21, 2, 8, 1e-6)
     gen_lanczos("n4p4r4c2_xe", 4, 4, 4, 2, 128, "xe", 64, 22, 1, 12, 1e-6)
-    gen_scipy("n4p3r4c1", "cg", 4, 3, 4, 1, 128, "square", 48, 23, 2, 15, 1e-6)
-    gen_scipy("n4p3r4c1", "minres", 4, 3, 4, 1, 128, "square", 48, 24, 2, 15, 1e-6)
+    gen_scipy("n4p3r4c1", "cg", 4, 3, 4, 1, 128, "square", 48, 23, 2, 5, 1e-6)
+    gen_scipy("n4p3r4c1", "minres", 4, 3, 4, 1, 128, "square", 48, 24, 2, 5, 1e-6)
 
     gen_qr("n5p4r6c1", 5, 4, 6, 1, 31)
     gen_qr("n4p3r4c3", 4, 3, 4, 3, 32)

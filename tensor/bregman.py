@@ -1,0 +1,5 @@
+"""`tensor.bregman` as the reference's callers import it; the implementation lives in tensornetworksfork_amd.tensor.bregman."""
+from tensornetworksfork_amd.tensor.bregman import *  # noqa: F401,F403
+from tensornetworksfork_amd.tensor import bregman as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith('__')})

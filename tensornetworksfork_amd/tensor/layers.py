@@ -1,0 +1,182 @@
+"""Topology builders with the reference's constructors (reference: tensor/layers.py).
+
+Only the shape / initialisation contract lives here: which nodes exist, their
+labels, bond sizes and the order in which random cores are drawn, so that a
+seeded layer starts from the same numbers as the reference.
+"""
+import torch
+import torch.nn as nn
+
+from .network import TensorNetwork
+from .node import TensorNode
+
+
+def _bond_pairs(N, r, f, constrict_bond):
+    """(left, right) bond per site.  With constrict_bond a bond never exceeds
+    what the sites on its smaller side can span: the schedule grows alternately
+    from both ends as min(r, previous*f) (tensor/layers.py:17-30,58-75)."""
+    if N == 1:
+        return [(1, 1)]
+
+    def grow(prev):
+        return min(r, prev * f) if constrict_bond else r
+
+    lefts = [(1, grow(1))]
+    rights = [(grow(1), 1)]
+    pairs = [lefts[0], rights[0]]
+    for i in range(N - 2):
+        open_left, open_right = lefts[-1][1], rights[0][0]
+        if i == N - 3:
+            pairs = lefts + [(open_left, open_right)] + rights
+        if i % 2 == 0:
+            lefts.append((open_left, grow(open_left)))
+        else:
+            rights.insert(0, (grow(open_right), open_right))
+    return pairs
+
+
+def _perturb_block(rl, f, rr, dtype):
+    """Identity-like block acting on the last physical index (tensor/layers.py:32-39)."""
+    core = torch.ones(rl, rr, dtype=dtype) if (rl == 1 or rr == 1) else torch.eye(rl, rr, dtype=dtype)
+    return torch.cat((torch.zeros(rl, f - 1, rr), core.unsqueeze(1)), dim=1).unsqueeze(1)
+
+
+class MainNodeLayer(nn.Module):
+    def __init__(self, N, r, f, output_shape=tuple(), down_label='p', horizontal_label='r{0}', constrict_bond=True,
+                 perturb=False, dtype=None):
+        """Cores A1..AN labelled [r_i, c_i|c, p, r_{i+1}] (tensor/layers.py:9-97)."""
+        super().__init__()
+        output_shape = output_shape if isinstance(output_shape, tuple) else (output_shape,)
+        if N == 1:
+            r = 1
+        self.labels = ['s']
+        if perturb:
+            first = _perturb_block(1, f, min(r, f) if constrict_bond else r, dtype)
+            first = first * (1 + 0.02 * torch.randn_like(first))
+            last = _perturb_block(r, f, 1, dtype)
+            last = last * (1 + 0.02 * torch.randn_like(last))
+            lefts, specs = [first], [first, last]
+            for i in range(N - 2):
+                rl, rr = lefts[-1].shape[-1], last.shape[0]
+                if i == N - 3:
+                    specs = lefts + [_perturb_block(rl, f, rr, dtype), last]
+                else:
+                    lefts.append(_perturb_block(rl, f, min(r, rl * f) if constrict_bond else r, dtype))
+            if N == 1:
+                specs = [first]
+        else:
+            specs = _bond_pairs(N, r, f, constrict_bond)
+        self.nodes = []
+        for i in range(1, N + 1):
+            if i - 1 < len(output_shape):
+                up, up_label = output_shape[i - 1], f'c{i}'
+                self.labels.append(up_label)
+            else:
+                up, up_label = 1, 'c'
+            left_label, right_label = horizontal_label.format(i), horizontal_label.format(i + 1)
+            spec = specs[i - 1]
+            if not perturb:
+                spec = (spec[0], up, f, spec[1])
+            self.nodes.append(TensorNode(spec, [left_label, up_label, down_label.format(i), right_label],
+                                         l=left_label, r=right_label, name=f"A{i}", dtype=dtype))
+
+
+class NodeLayer(nn.Module):
+    def __init__(self, N, size, labels, name='L{0}', dtype=None):
+        super().__init__()
+        self.nodes = [TensorNode(size, [lab.format(i) for lab in labels], name=name.format(i), dtype=dtype)
+                      for i in range(1, N + 1)]
+
+
+class InputNodeLayer(NodeLayer):
+    def __init__(self, N, f, label='p', dtype=None):
+        """Placeholder inputs X1..XN of shape (1, f); they consume random draws like the reference's."""
+        super().__init__(N, (1, f), ['s', label], name='X{0}', dtype=dtype)
+
+
+class TensorNetworkLayer(nn.Module):
+    def __init__(self, tensor_network: TensorNetwork = None):
+        super().__init__()
+        self.set_tensor_network(tensor_network)
+
+    def set_tensor_network(self, tensor_network: TensorNetwork = None):
+        self.tensor_network = tensor_network
+        self.labels = tensor_network.output_labels if tensor_network is not None else None
+        self.parametrized = False
+        self.nodes = tensor_network.train_nodes if tensor_network is not None else []
+
+    def node_states(self, detach=True):
+        """{"tensor_param_i": core i}; cloned unless detach is False (tensor/layers.py:127-135)."""
+        return {f"tensor_param_{i}": (n.tensor.detach().clone() if detach else n.tensor)
+                for i, n in enumerate(self.tensor_network.train_nodes)}
+
+    def load_node_states(self, tensor_params, set_value=False):
+        for i, n in enumerate(self.tensor_network.train_nodes):
+            key = f"tensor_param_{i}"
+            if key not in tensor_params:
+                raise ValueError(f"Missing parameter: {key}")
+            if set_value:
+                n.tensor = tensor_params[key]
+            else:
+                n.tensor.data.copy_(tensor_params[key].detach().clone())
+        self.tensor_network.reset_stacks()
+
+    def cuda(self, *args, **kwargs):
+        self.tensor_network.cuda()
+        return super().cuda(*args, **kwargs)
+
+    def to(self, *args, **kwargs):
+        self.tensor_network.to(*args, **kwargs)
+        return super().to(*args, **kwargs)
+
+    def cpu(self, *args, **kwargs):
+        self.tensor_network.to('cpu')
+        return super().cpu(*args, **kwargs)
+
+    def forward(self, x, to_tensor=True):
+        out = self.tensor_network.forward(x)
+        if self.labels is not None:
+            out.permute_first(*self.labels)
+        return out.tensor if to_tensor else out
+
+    def num_parameters(self):
+        return sum(n.tensor.numel() for n in self.tensor_network.train_nodes)
+
+    def zip_connect(self, nodes1, nodes2, label='p', priority=-1):
+        if len(nodes1) != len(nodes2):
+            raise ValueError("The number of nodes in both lists must be the same.")
+        for i, (a, b) in enumerate(zip(nodes1, nodes2), 1):
+            a.connect(b, label.format(i), priority=priority)
+
+    def horizontal_connect(self, nodes):
+        for a, b in zip(nodes[:-1], nodes[1:]):
+            if a.right_labels and b.left_labels and a.right_labels[0] != b.left_labels[0]:
+                raise ValueError(f"Right label of the first node does not match left label of the second node. "
+                                 f"Nodes: {a.name}, {b.name}")
+            a.connect(b, a.right_labels[0], priority=1)
+
+
+class TensorTrainLayer(TensorNetworkLayer):
+    def __init__(self, num_carriages, bond_dim, input_features, output_shape=tuple(), squeeze=True, constrict_bond=True,
+                 perturb=False, dtype=None, seed=None):
+        """Plain tensor train: cores first, then placeholder inputs, under one seed (tensor/layers.py:194-221)."""
+        super().__init__()
+        self.num_carriages = num_carriages
+        self.bond_dim = bond_dim
+        self.input_features = input_features
+        self.output_shape = output_shape if isinstance(output_shape, tuple) else (output_shape,)
+        if seed is not None:
+            torch.manual_seed(seed)
+            if torch.cuda.is_available():
+                torch.cuda.manual_seed(seed)
+        self.main_node_layer = MainNodeLayer(num_carriages, bond_dim, input_features, output_shape=output_shape,
+                                             down_label='p{0}', constrict_bond=constrict_bond, perturb=perturb,
+                                             dtype=dtype)
+        self.horizontal_connect(self.main_node_layer.nodes)
+        self.input_node_layer = InputNodeLayer(num_carriages, input_features, label='p{0}', dtype=dtype)
+        self.zip_connect(self.input_node_layer.nodes, self.main_node_layer.nodes, label='p{0}')
+        if squeeze:
+            for n in self.main_node_layer.nodes:
+                n.squeeze(self.main_node_layer.labels)
+        self.set_tensor_network(TensorNetwork(self.input_node_layer.nodes, self.main_node_layer.nodes,
+                                              output_labels=self.main_node_layer.labels))
