@@ -1,0 +1,232 @@
+"""DMRG core-update benchmark: 16-site, bond-32, degree-5 tensor train on a 60k-sample synthetic set.
+
+    python bench.py --gpus 1 --steps 12 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one core update of a middle site (rl = rr = 32, p = 6, D = 6144) over all 54 000
+training samples through the public drop-in API (TensorNetwork.accumulating_swipe with
+method='ridge_cholesky', orthonormalize=True, i.e. what TNMLRegressor.fit runs): environment
+refresh, prediction, loss, Gram + RHS build, scaled ridge Cholesky solve, core update, QR
+gauge move, and the per-update validation pass of the estimator's early-stopping hook.
+With N > 1 the training samples are sharded over the ranks (strong scaling) and one
+all-reduce of [compressed Gram | RHS] precedes the replicated solve.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the Gram kernel (HIP events recorded on its
+launch stream inside the timed region); `cpu_baseline` is the CPU oracle (oracle/tt_oracle.py)
+timed on the host cores on a bounded sample; `variants.cg` is the matrix-free CG path (N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SITES, BOND, DEGREE, S_ALL, N_FEAT = 16, 32, 5, 60000, 16
+FP64_MFMA_PEAK_TFLOPS = 78.6    # MI355X dense fp64 matrix peak (v_mfma_f64_16x16x4: 64 cycles/SIMD at 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_problem(device):
+    from tensornetworksfork_amd.models._common import split_train_val
+    from tensornetworksfork_amd.models.tnml import polynomial_basis
+    rng = np.random.RandomState(0)
+    X = rng.uniform(-1, 1, (S_ALL, N_FEAT))
+    y = np.sin(X).sum(1, keepdims=True) + 0.01 * rng.randn(S_ALL, 1)
+    X = torch.tensor(X, dtype=torch.float64, device=device)
+    y = torch.tensor(y, dtype=torch.float64, device=device)
+    Xt, yt, Xv, yv = split_train_val(X, y, 42, 0.1)
+    return polynomial_basis(Xt, DEGREE), yt.contiguous(), polynomial_basis(Xv, DEGREE), yv.contiguous()
+
+
+def make_model(device):
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    layer = TensorTrainLayer(N_SITES, BOND, DEGREE + 1, output_shape=1, constrict_bond=True, seed=42).to(device)
+    layer.tensor_network.orthonormalize_left()
+    return layer
+
+
+class StepCounter:
+    """convergence_criterion hook: validation RMSE after every update (as EarlyStopping does),
+    stop after `limit` updates."""
+
+    def __init__(self, tn, F_val, y_val, limit):
+        from tensornetworksfork_amd.models._common import root_mean_squared_error_torch
+        self.tn, self.F_val, self.y_val, self.limit = tn, F_val, y_val, limit
+        self.rmse = root_mean_squared_error_torch
+        self.count = 0
+        self.last = None
+
+    def __call__(self):
+        self.last = self.rmse(self.y_val, self.tn.forward_batch(self.F_val, 512))
+        self.count += 1
+        return self.count >= self.limit
+
+
+def run_updates(tn, F, y, F_val, y_val, n_updates, eps0=1.0):
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    mid = tn.main_nodes[2:N_SITES - 2]
+    hook = StepCounter(tn, F_val, y_val, n_updates)
+    tn.accumulating_swipe(F, y, SquareBregFunction(), node_order=(mid, mid), batch_size=512, lr=1.0, eps=eps0,
+                          eps_decay=0.5, convergence_criterion=hook, orthonormalize=True, method='ridge_cholesky',
+                          num_swipes=10 ** 6, direction='l2r')
+    assert hook.count == n_updates
+    return hook.last
+
+
+def cg_variant(device, F, y, steps):
+    """Matrix-free CG (scipy.sparse.linalg.cg semantics, max_iter=100, rtol=1e-6) on middle sites."""
+    import scipy.sparse.linalg as spla
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    layer = make_model(device)
+    tn = layer.tensor_network
+    all_nodes = tn.train_nodes
+    try:
+        tn.train_nodes = tn.main_nodes[2:3]
+        tn.scipy_swipe(F, y, SquareBregFunction(), spla.cg, batch_size=512, max_iter=100, tol=1e-6)   # warm-up
+        tn.train_nodes = tn.main_nodes[3:3 + steps]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tn.scipy_swipe(F, y, SquareBregFunction(), spla.cg, batch_size=512, max_iter=100, tol=1e-6)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        tn.train_nodes = all_nodes
+    S, D = F[0].shape[0], BOND * (DEGREE + 1) * BOND
+    per = dt / steps
+    it_bytes = S * (BOND + DEGREE + 1 + BOND + 2) * 8.0
+    return {"value": 1.0 / per, "unit": "core-updates/s", "ms_per_step": per * 1e3, "steps": steps, "max_iter": 100,
+            "rtol": 1e-6, "samples_per_sec": S / per,
+            "matvec_algorithmic": {"flops_per_iter": 4.0 * S * D, "bytes_per_iter": it_bytes,
+                                   "iters_per_update_upper_bound": 101,
+                                   "hbm_gbs_lower_bound": 101 * it_bytes / per * 1e-9,
+                                   "hbm_frac_lower_bound": 101 * it_bytes / per * 1e-9 / HBM_PEAK_GBS}}
+
+
+def cpu_baseline(sample=8192):
+    """The CPU oracle on the host cores: environments + Gram/RHS of a middle site on `sample` of the
+    54 000 training samples (extrapolated linearly in the sample count) plus the full D=6144 solve."""
+    from oracle import tt_oracle as O
+    rng = np.random.RandomState(0)
+    X = torch.tensor(rng.uniform(-1, 1, (sample, N_FEAT)))
+    y = torch.tensor(np.sin(X.numpy()).sum(1, keepdims=True))
+    xs = O.polynomial_basis(X, DEGREE)
+    cores = O.init_tt_cores(N_SITES, BOND, DEGREE + 1, 1, True, seed=42, dtype=torch.float64)
+    k = 7
+    t0 = time.perf_counter()
+    A, b, loss, g, H = O.site_problem(cores, xs, k, y, 'square')
+    t_gram = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    step = O.solve_system(A, b, O.canon(cores)[k], 'ridge_cholesky', 1.0)
+    t_solve = time.perf_counter() - t0
+    S_train = int(S_ALL * 0.9)
+    per = t_gram * (S_train / sample) + t_solve
+    return {"value": 1.0 / per, "unit": "core-updates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle envs+Gram+RHS on {sample} of {S_train} samples ({t_gram:.2f} s, scaled x{S_train / sample:.2f}) "
+                      f"+ full D=6144 ridge_cholesky solve ({t_solve:.2f} s)",
+            "samples_per_sec": S_train / per, "step_norm": float(step.norm())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8192)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.set_default_dtype(torch.float64)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from tensornetworksfork_amd import ops
+    F, y, F_val, y_val = synthetic_problem(device)
+    layer = make_model(device)
+    tn = layer.tensor_network
+    if world > 1:
+        tn.distribute("auto")
+    S_train = F[0].shape[0]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run_updates(tn, F, y, F_val, y_val, args.warmup)
+    ops.gram_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    val_rmse = run_updates(tn, F, y, F_val, y_val, args.steps, eps0=0.5)
+    fence()
+    elapsed = time.perf_counter() - t0
+    gram_ms = ops.gram_timing_read()
+    ops.gram_timing(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    ups = args.steps / elapsed
+    S_local = S_train // world + (1 if S_train % world else 0)
+    MP = BOND * (BOND + 1) // 2
+    NX = (DEGREE + 1) * (DEGREE + 2) // 2
+    gram_flops = 2.0 * S_local * MP * NX * MP           # distinct entries of the symmetric Gram x samples
+    D = BOND * (DEGREE + 1) * BOND
+    avg_ms = float(np.mean(gram_ms)) if gram_ms else float("nan")
+    achieved = gram_flops / (avg_ms * 1e-3) * 1e-12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "gram_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "dmrg_core_updates_per_sec", "value": ups, "unit": "core-updates/s",
+        "samples_per_sec": ups * S_train, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cfg2 TNML tensor train: 16 sites, bond 32, polynomial degree 5 (p=6), 60000x16 synthetic "
+                               "samples (54000 train / 6000 val); middle-site core updates (D=6144) via "
+                               "accumulating_swipe(method='ridge_cholesky', orthonormalize=True) incl. per-update "
+                               "validation pass; CG variant under variants.cg",
+                   "sites": N_SITES, "bond": BOND, "degree": DEGREE, "train_samples": S_train, "D": D,
+                   "batch_size": 512, "sharding": f"samples/{world}", "val_rmse": val_rmse},
+        "roofline": {"kernel": "gram_kernel<true>", "bound": "mfma", "achieved": achieved,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": traffic, "launches": len(gram_ms), "avg_launch_ms": avg_ms,
+                     "flops_per_launch": gram_flops,
+                     "dense_equivalent_tflops": 2.0 * S_local * D * D / (avg_ms * 1e-3) * 1e-12},
+    }
+    if rank == 0 and world == 1 and not args.no_variants:
+        out["variants"] = {"cg": cg_variant(device, F, y, steps=4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

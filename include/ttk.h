@@ -83,6 +83,15 @@ int ttk_gram_scale_f64(const void* ws, int rl, int p, int rr, int sym_left, doub
 int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, const double* scale,
                         double ridge, double* A_out, void* stream);
 
+/* Timing of the Gram kernel with HIP events recorded on the launch stream (no
+ * counterpart in the reference; used by bench.py for the roofline figure).
+ * ttk_gram_timing(1) creates a pool of event pairs and arms recording around every
+ * subsequent Gram kernel launch; ttk_gram_timing(0) disarms.  ttk_gram_timing_read
+ * waits for the recorded pairs, writes up to `max` durations (milliseconds, launch
+ * order) to ms_out (HOST pointer), clears the list and returns how many it wrote. */
+int ttk_gram_timing(int enable);
+int ttk_gram_timing_read(double* ms_out, int max);
+
 /* Right-hand side / transposed Jacobian product
  *   b[l,p,r] = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]
  * (get_A_b / get_b, tensor/network.py:215,289; second einsum of the matrix-free

@@ -646,10 +646,41 @@ __global__ __launch_bounds__(256) void axpy_kernel(const double* __restrict__ a,
   if (idx < n) y[idx] += sign * a[0] * x[idx];
 }
 
+// Event pairs around the Gram kernel (diagnostic; armed by ttk_gram_timing).
+static const int kTimingPool = 512;
+static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
+static bool g_ev_created = false, g_ev_armed = false;
+static int g_ev_count = 0;
+
 // =======================================================================================
 // C ABI
 // =======================================================================================
 extern "C" {
+
+int ttk_gram_timing(int enable) {
+  if (enable && !g_ev_created) {
+    for (int k = 0; k < kTimingPool; ++k) {
+      if (hipEventCreate(&g_ev_start[k]) != hipSuccess || hipEventCreate(&g_ev_stop[k]) != hipSuccess) return TTK_ELAUNCH;
+    }
+    g_ev_created = true;
+  }
+  g_ev_armed = enable != 0;
+  g_ev_count = 0;
+  return TTK_OK;
+}
+
+int ttk_gram_timing_read(double* ms_out, int max) {
+  if (!ms_out || max < 0) return TTK_EINVAL;
+  int n = 0;
+  for (int k = 0; k < g_ev_count && n < max; ++k) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_ev_stop[k]) != hipSuccess) return TTK_ELAUNCH;
+    if (hipEventElapsedTime(&ms, g_ev_start[k], g_ev_stop[k]) != hipSuccess) return TTK_ELAUNCH;
+    ms_out[n++] = (double)ms;
+  }
+  g_ev_count = 0;
+  return n;
+}
 
 int ttk_version(void) { return 100; }
 
@@ -718,12 +749,15 @@ int ttk_gram_f64(const double* L, const double* HL, const double* X, const doubl
   double* partial = d.nslabs > 1 ? G + d.gsize : G;
   const size_t lds = (size_t)d.CH * (2 * C * rl + p + rr) * sizeof(double);
   const unsigned grid = (unsigned)d.ngroups * (unsigned)d.nslabs;
+  const bool timed = g_ev_armed && g_ev_count < kTimingPool;
+  if (timed) hipEventRecord(g_ev_start[g_ev_count], st);
   if (C == 1)
     hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds, st, L, HL, X, R, S, C, rl, p, rr, sym_left, d,
                        partial);
   else
     hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds, st, L, HL, X, R, S, C, rl, p, rr, sym_left, d,
                        partial);
+  if (timed) hipEventRecord(g_ev_stop[g_ev_count++], st);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 1) {

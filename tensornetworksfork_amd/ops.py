@@ -104,6 +104,14 @@ def hess_left(H, L):
     return HL
 
 
+def gram_gsize(rl, p, rr, sym):
+    """Number of doubles of the compressed Gram [pairs(l,m) -> 48][pairs(p,q)][pairs(r,t) -> 48]."""
+    def up48(v):
+        return (v + 47) // 48 * 48
+    mp = rl * (rl + 1) // 2 if sym else rl * rl
+    return up48(mp) * (p * (p + 1) // 2) * up48(rr * (rr + 1) // 2)
+
+
 class GramWorkspace:
     """Symmetry-compressed Gram matrix held in a device workspace."""
 
@@ -114,6 +122,12 @@ class GramWorkspace:
             raise _lib.TTKError("ttk_gram_ws_bytes: invalid extents")
         self.nbytes = int(nbytes)
         self.buf = torch.empty((self.nbytes + 7) // 8, dtype=F64, device=device)
+        self.gsize = gram_gsize(int(rl), int(p), int(rr), bool(sym))
+
+    @property
+    def compressed(self):
+        """The reduced compressed Gram (what a multi-rank all-reduce sums)."""
+        return self.buf[:self.gsize]
 
 
 def gram(L, HL, X, R, sym=True, ws=None):
@@ -212,3 +226,18 @@ def axpy(a, x, y, sign=1.0):
     rc = _lib.lib().ttk_axpy_f64(_chk(a, "a"), float(sign), _chk(x, "x"), _chk(y, "y"), x.numel(), _stream(x))
     _lib.check(rc, "ttk_axpy_f64")
     return y
+
+
+def gram_timing(enable):
+    """Arm / disarm HIP-event timing of the Gram kernel (see ttk_gram_timing)."""
+    _lib.check(_lib.lib().ttk_gram_timing(1 if enable else 0), "ttk_gram_timing")
+
+
+def gram_timing_read(max_n=512):
+    """Durations (ms) of the Gram kernel launches recorded since the last read."""
+    import ctypes
+    buf = (ctypes.c_double * max_n)()
+    n = _lib.lib().ttk_gram_timing_read(ctypes.cast(buf, ctypes.c_void_p), max_n)
+    if n < 0:
+        _lib.check(n, "ttk_gram_timing_read")
+    return [buf[i] for i in range(n)]
