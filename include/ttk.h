@@ -70,13 +70,13 @@ int ttk_hess_left_f64(const double* H, const double* L, double* HL, int64_t S, i
  *   A[(l,p,r),(m,q,t)] = sum_{s,c,d} H[s,c,d] L[s,c,l]X[s,p]R[s,r] L[s,d,m]X[s,q]R[s,t]
  * (get_A_b, tensor/network.py:174-212, summed over mini-batches as in 463-468).
  * Computed in symmetry-compressed form into ws, then expanded:
- *   ttk_gram_f64        -> compressed G in ws  (needs HL from ttk_hess_left_f64)
+ *   ttk_gram_f64        -> compressed G in ws  (H (S,C,C) is the per-sample Hessian)
  *   ttk_gram_scale_f64  -> scale[0] = mean_i |A_ii| (1 if 0)      (network.py:298-300)
  *   ttk_gram_expand_f64 -> A_out (D,D) = A / scale[0] + ridge*I   (network.py:301,308,312)
  *                          (scale == NULL means 1).
  * sym_left != 0 asserts H[s] symmetric (exploits l<->m symmetry). */
 int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left);
-int ttk_gram_f64(const double* L, const double* HL, const double* X, const double* R,
+int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R,
                  int64_t S, int C, int rl, int p, int rr, int sym_left,
                  void* ws, int64_t ws_bytes, void* stream);
 int ttk_gram_scale_f64(const void* ws, int rl, int p, int rr, int sym_left, double* scale, void* stream);
@@ -111,6 +111,22 @@ int ttk_jvp_f64(const double* L, const double* X, const double* R, const double*
  * scale == NULL means 1; w == NULL means no shift. */
 int ttk_solve_rhs_f64(const double* b, const double* w, const double* scale, double ridge, double* out,
                       int64_t D, void* stream);
+
+/* Cholesky solve of the scaled, ridge-shifted normal equations, replacing
+ * torch.linalg.cholesky + torch.cholesky_solve in solve_system
+ * (tensor/network.py:311-320).  Blocked right-looking factorisation (64-wide panels,
+ * fp64 MFMA trailing updates) with the right-hand side carried as an extra block row.
+ *   ttk_chol_ws_bytes(n)  -> bytes of the factorisation workspace for order n
+ *   ttk_chol_prepare_f64  -> fills the workspace from a compressed Gram (see ttk_gram_f64):
+ *                            lower triangle of A/scale[0] + ridge*I and the right-hand side
+ *                            -(b/scale[0] + ridge*w)        (network.py:301-302,312-313,315)
+ *   ttk_chol_solve_f64    -> x (n) = solution; info[0] (device int) = 0, or the 1-based order
+ *                            of the first non-positive pivot (torch.linalg.LinAlgError in
+ *                            the reference, network.py:481-484). */
+int64_t ttk_chol_ws_bytes(int n);
+int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
+                         const double* b, const double* w, void* chol_ws, void* stream);
+int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream);
 
 /* Krylov vector kernels with wavefront-shuffle reductions (lanczos_solver,
  * tensor/network.py:796-824): out[0] = <x,y>;  y += a[0]*x  (a on device);

@@ -36,6 +36,9 @@ SIGNATURES = {
     "ttk_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_jvp_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_solve_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _dbl, _c_dp, _i64, _c_dp]),
+    "ttk_chol_ws_bytes": (_i64, [_int]),
+    "ttk_chol_prepare_f64": (_int, [_c_dp, _int, _int, _int, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "ttk_chol_solve_f64": (_int, [_c_dp, _int, _c_dp, _c_dp, _c_dp]),
     "ttk_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_axpy_f64": (_int, [_c_dp, _dbl, _c_dp, _c_dp, _i64, _c_dp]),
 }

@@ -310,27 +310,70 @@ static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym) {
   d.nslabs = want < 1 ? 1 : want;
   d.slab_len = round_up64((S + d.nslabs - 1) / d.nslabs, 4);
   // chunk of samples staged in LDS: (2*C*rl + p + rr) doubles per sample, <= 56 KiB
-  const int width = 2 * C * rl + p + rr;
-  int ch = (56 * 1024) / (width * 8);
+  const int width = 2 * C * rl + d.NX + rr + 1;
+  int ch = (16 * 256) / width;   // GRAM_NLD (16) loads per thread cover one chunk (32 KiB of LDS at most)
   ch = ch / 4 * 4;
   if (ch > 64) ch = 64;
   d.CH = ch;
   return d;
 }
 
+// Packed per-sample factor table
+//   F[s] = [ L[s,:,:] | HL[s,:,:] | XX[s,:] | R[s,:] | 0 ]      (W = 2*C*rl + p(p+1)/2 + rr + 1 doubles)
+// with HL[s,d,l] = sum_c H[s,c,d] L[s,c,l] and XX[s,(p<=q)] = X[s,p] X[s,q].  One contiguous row
+// range of F is the LDS image of a sample chunk, so the Gram kernel stages a chunk with one
+// batch of unconditional loads; the trailing zero is where lanes of padded tile rows/columns
+// point, so that padding needs no mask multiply (fp64 VALU multiplies and fp64 MFMA share one
+// datapath on gfx950: every v_mul_f64 in the inner loop costs MFMA issue time).
+__global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict__ L, const double* __restrict__ H,
+                                                         const double* __restrict__ X, const double* __restrict__ R,
+                                                         int64_t S, int C, int rl, int p, int rr,
+                                                         double* __restrict__ F) {
+  const int CW = C * rl, NX = p * (p + 1) / 2, W = 2 * CW + NX + rr + 1;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * W) return;
+  const int64_t s_ = idx / W;
+  const int j = (int)(idx - s_ * W);
+  double v = 0.0;
+  if (j < CW) {
+    v = L[s_ * CW + j];
+  } else if (j < 2 * CW) {
+    const int d = (j - CW) / rl, l = (j - CW) - d * rl;
+    for (int c = 0; c < C; ++c) v += H[(s_ * C + c) * C + d] * L[(s_ * C + c) * rl + l];
+  } else if (j < 2 * CW + NX) {
+    int pp, qq;
+    tri_decode(j - 2 * CW, p, pp, qq);
+    v = X[s_ * p + pp] * X[s_ * p + qq];
+  } else if (j < 2 * CW + NX + rr) {
+    v = R[s_ * rr + (j - 2 * CW - NX)];
+  }
+  F[idx] = v;
+}
+
+#define GRAM_NLD 16
+// One chunk = `total` consecutive doubles of F starting at `g`; elements past `valid` (end of
+// the slab) read as zero.  The loads are unconditional (clamped index) so that they leave as
+// one batch; a load under a per-element branch would be waited for one by one.
+__device__ __forceinline__ void gram_chunk_load(const double* __restrict__ g, int valid, int tid,
+                                                double (&v)[GRAM_NLD]) {
+#pragma unroll
+  for (int e = 0; e < GRAM_NLD; ++e) {
+    const int idx = e * 256 + tid;
+    const double x = g[min(idx, valid - 1)];
+    v[e] = idx < valid ? x : 0.0;
+  }
+}
+
 template <bool C1>
-__global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ L, const double* __restrict__ HL,
-                                                       const double* __restrict__ X, const double* __restrict__ R,
-                                                       int64_t S, int C, int rl, int p, int rr, int sym, GramDims gd,
-                                                       double* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ F, int64_t S, int C, int rl, int p,
+                                                       int rr, int sym, GramDims gd, double* __restrict__ partial) {
   extern __shared__ double smem[];
   const int CW = C * rl;
   const int CH = gd.CH;
-  double* Ls = smem;
-  double* HLs = Ls + (size_t)CH * CW;
-  double* Xs = HLs + (size_t)CH * CW;
-  double* Rs = Xs + (size_t)CH * p;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int W = 2 * CW + gd.NX + rr + 1;
+  const int total = CH * W;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int slab = blockIdx.x % gd.nslabs;
   const int group = blockIdx.x / gd.nslabs;
   const int tile = group * 4 + wave;
@@ -342,24 +385,34 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
     tm = rem / gd.ntn;
     tn = rem - tm * gd.ntn;
   }
-  int pb, qb;
-  tri_decode(b, p, pb, qb);
-  int la[3], ma[3], rc[3], tc[3];
-  double am[3], cm[3];
+  // element offsets inside a sample row of the chunk image; W - 1 is the zero column
+  const int oX = 2 * CW + b;
+  int oH[3], oL[3], oR1[3], oR2[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int a = tm * 48 + u * 16 + i;
-    am[u] = a < gd.MP ? 1.0 : 0.0;
-    const int aa = a < gd.MP ? a : 0;
-    if (sym) {
-      tri_decode(aa, rl, la[u], ma[u]);
+    int l_ = 0, m_ = 0;
+    if (a < gd.MP) {
+      if (sym) {
+        tri_decode(a, rl, l_, m_);
+      } else {
+        l_ = a / rl;
+        m_ = a - l_ * rl;
+      }
+      oH[u] = CW + l_;
+      oL[u] = m_;
     } else {
-      la[u] = aa / rl;
-      ma[u] = aa - la[u] * rl;
+      oH[u] = oL[u] = W - 1;
     }
     const int c = tn * 48 + u * 16 + i;
-    cm[u] = c < gd.NR ? 1.0 : 0.0;
-    tri_decode(c < gd.NR ? c : 0, rr, rc[u], tc[u]);
+    if (c < gd.NR) {
+      int r_, t_;
+      tri_decode(c, rr, r_, t_);
+      oR1[u] = 2 * CW + gd.NX + r_;
+      oR2[u] = 2 * CW + gd.NX + t_;
+    } else {
+      oR1[u] = oR2[u] = W - 1;
+    }
   }
   d4 acc[3][3];
 #pragma unroll
@@ -370,45 +423,38 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   const int64_t s_begin = (int64_t)slab * gd.slab_len;
   int64_t s_end = s_begin + gd.slab_len;
   if (s_end > S) s_end = S;
+  double pre[GRAM_NLD];
+  if (s_begin < s_end)
+    gram_chunk_load(F + s_begin * W, (int)min((int64_t)CH, s_end - s_begin) * W, tid, pre);
   for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
     const int64_t nvalid = min((int64_t)CH, s_end - c0);
     __syncthreads();
-    {
-      const int64_t nLe = nvalid * CW;
-      const double* gL = L + c0 * CW;
-      const double* gH = HL + c0 * CW;
-      for (int idx = threadIdx.x; idx < CH * CW; idx += 256) {
-        const bool ok = idx < nLe;
-        Ls[idx] = ok ? gL[idx] : 0.0;
-        HLs[idx] = ok ? gH[idx] : 0.0;
-      }
-      const double* gX = X + c0 * p;
-      for (int idx = threadIdx.x; idx < CH * p; idx += 256) Xs[idx] = idx < nvalid * p ? gX[idx] : 0.0;
-      const double* gR = R + c0 * rr;
-      for (int idx = threadIdx.x; idx < CH * rr; idx += 256) Rs[idx] = idx < nvalid * rr ? gR[idx] : 0.0;
+#pragma unroll
+    for (int e = 0; e < GRAM_NLD; ++e) {
+      const int idx = e * 256 + tid;
+      if (idx < total) smem[idx] = pre[e];
     }
     __syncthreads();
+    if (c0 + CH < s_end)
+      gram_chunk_load(F + (c0 + CH) * W, (int)min((int64_t)CH, s_end - c0 - CH) * W, tid, pre);
     if (active) {
       const int steps = (int)((nvalid + 3) >> 2);
       for (int ks = 0; ks < steps; ++ks) {
-        const int s = ks * 4 + kq;
-        const double* Lrow = Ls + s * CW;
-        const double* Hrow = HLs + s * CW;
-        const double* Xrow = Xs + s * p;
-        const double* Rrow = Rs + s * rr;
-        const double xx = Xrow[pb] * Xrow[qb];
+        const double* row = smem + (ks * 4 + kq) * W;
+        const double xx = row[oX];
         double aop[3], bop[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           double pa;
           if (C1) {
-            pa = Hrow[la[u]] * Lrow[ma[u]];
+            pa = row[oH[u]] * row[oL[u]];
           } else {
             pa = 0.0;
-            for (int d = 0; d < C; ++d) pa += Hrow[d * rl + la[u]] * Lrow[d * rl + ma[u]];
+            if (oL[u] != W - 1)
+              for (int d = 0; d < C; ++d) pa += row[oH[u] + d * rl] * row[oL[u] + d * rl];
           }
-          aop[u] = pa * xx * am[u];
-          bop[u] = Rrow[rc[u]] * Rrow[tc[u]] * cm[u];
+          aop[u] = pa * xx;
+          bop[u] = row[oR1[u]] * row[oR2[u]];
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u)
@@ -646,6 +692,351 @@ __global__ __launch_bounds__(256) void axpy_kernel(const double* __restrict__ a,
   if (idx < n) y[idx] += sign * a[0] * x[idx];
 }
 
+// ---------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky with the right-hand side carried as an extra block row.
+//
+// Storage: `aug` is ((nb+1)*64) x ld row-major, ld = nb*64.  Rows < nb*64 hold the SPD
+// matrix (lower triangle is read; order n padded to nb*64 with an identity block), block
+// row nb holds the right-hand side in its first row and zeros below.  Because
+// [A b; b^T .] = [L 0; y^T .][L^T y; 0 .] the forward substitution y = L^-1 b falls out of
+// the panel solves of that extra row.  Per 64-column panel j:
+//   chol_diag_kernel  : L_jj = chol(A_jj) and its inverse, inside one workgroup's LDS;
+//   chol_panel_kernel : L_ij = A_ij * inv(L_jj)^T for every block row i > j      (MFMA);
+//   chol_syrk_kernel  : A_ik -= L_i,panel * L_k,panel^T on the lower trailing blocks (MFMA).
+// Panels are applied to the trailing matrix two at a time (K = 128) so that the trailing
+// matrix, which is what bounds this factorisation (HBM read+write per panel), is swept
+// half as often; the block column in between gets a narrow K = 64 update.
+// The backward substitution x = L^-T y walks the block rows upward, one launch per block.
+// ---------------------------------------------------------------------------------------
+#define CHB 64
+
+// 1/sqrt(d) from the hardware estimate plus two Newton steps (full double precision), and
+// sqrt(d) = d * rsqrt(d) with one correction; much shorter dependency chain than sqrt + divide.
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  double s = d * y;
+  s = fma(0.5 * y, fma(-s, s, d), s);
+  rs = y;
+  sq = s;
+}
+
+// Panel j in one launch.  Every workgroup factorises the 64x64 diagonal block A_jj in
+// registers (thread (r,q) owns row r, columns c = q mod 4; one barrier per column), then
+// workgroup 0 stores L_jj and workgroup b >= 1 solves X L_jj^T = A_ij for block row
+// i = j + b by a right-looking substitution along its rows (4 lanes per row, no barrier).
+// Recomputing the small factorisation everywhere removes a launch and a global round trip
+// from the critical path.  With `fuse` set the pending update of block column j by the
+// previous panel (A_ij -= L_i,j-1 L_j,j-1^T, K = 64, MFMA) is applied on the fly first, so
+// that panels can be applied to the rest of the trailing matrix two at a time.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ aug, int ld, int j, int fuse,
+                                                          int* __restrict__ info) {
+  __shared__ double T[CHB][CHB + 1];
+  __shared__ double B0[CHB][CHB + 1];
+  __shared__ double B1[CHB][CHB + 1];
+  __shared__ double colbuf[2][CHB];
+  __shared__ double rdiag[CHB];
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, q = tid & 3;
+  const int i = j + blockIdx.x;   // block row of this workgroup (== j: stores the factor)
+  const double* diag = aug + ((int64_t)j * CHB) * ld + (int64_t)j * CHB;
+  double* blk = aug + ((int64_t)i * CHB) * ld + (int64_t)j * CHB;
+  if (fuse) {
+    // B0[kk][r] = L_j,j-1[r][kk],  B1[kk][r] = L_i,j-1[r][kk]
+    const double* Pd = aug + ((int64_t)j * CHB) * ld + (int64_t)(j - 1) * CHB;
+    const double* Pi = aug + ((int64_t)i * CHB) * ld + (int64_t)(j - 1) * CHB;
+    for (int idx = tid; idx < CHB * CHB; idx += 256) {
+      const int rr_ = idx >> 6, kk = idx & 63;
+      B0[kk][rr_] = Pd[(int64_t)rr_ * ld + kk];
+      B1[kk][rr_] = Pi[(int64_t)rr_ * ld + kk];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    d4 ud[4], ui[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ud[t] = ui[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < CHB; k0 += 4) {
+      const double ad = B0[k0 + kq][wave * 16 + li];
+      const double ai = B1[k0 + kq][wave * 16 + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = B0[k0 + kq][t * 16 + li];
+        ud[t] = MFMA_F64(ad, b, ud[t]);
+        ui[t] = MFMA_F64(ai, b, ui[t]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        B0[wave * 16 + kq + 4 * u][t * 16 + li] = ud[t][u];
+        B1[wave * 16 + kq + 4 * u][t * 16 + li] = ui[t][u];
+      }
+    __syncthreads();
+  }
+  double a[16];
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) {
+    const int c = 4 * sl + q;
+    double v = (c <= r) ? diag[(int64_t)r * ld + c] : 0.0;
+    if (fuse && c <= r) v -= B0[r][c];
+    a[sl] = v;
+  }
+  bool bad = false;
+  int badcol = 0;
+#pragma unroll
+  for (int c = 0; c < CHB; ++c) {
+    const int sl = c >> 2, qo = c & 3;
+    if (q == qo) colbuf[c & 1][r] = a[sl];
+    __syncthreads();
+    double d = colbuf[c & 1][c];
+    if (!(d > 0.0)) {
+      if (!bad) badcol = c;
+      bad = true;
+      d = 1.0;
+    }
+    double rs, sq;
+    rsqrt_sqrt(d, rs, sq);
+    const double my_l = colbuf[c & 1][r] * rs;
+#pragma unroll
+    for (int s2 = sl; s2 < 16; ++s2) {
+      const int cc = 4 * s2 + q;
+      const double lc = colbuf[c & 1][cc] * rs;
+      if (cc > c) a[s2] -= my_l * lc;
+    }
+    if (q == qo) {
+      a[sl] = (r == c) ? sq : my_l;
+      if (r == c) rdiag[c] = rs;
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) T[r][4 * sl + q] = a[sl];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (bad && tid == 0 && *info == 0) *info = j * CHB + badcol + 1;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+      const int c = 4 * sl + q;
+      if (c <= r) blk[(int64_t)r * ld + c] = a[sl];
+    }
+    return;
+  }
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) {
+    double v = blk[(int64_t)r * ld + 4 * sl + q];
+    if (fuse) v -= B1[r][4 * sl + q];
+    a[sl] = v;
+  }
+  const int lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < CHB; ++c) {
+    const int sl = c >> 2, qo = c & 3;
+    const double mine = a[sl] * rdiag[c];
+    const double x = __shfl(mine, (lane & ~3) | qo, 64);
+    if (q == qo) a[sl] = x;
+#pragma unroll
+    for (int s2 = sl; s2 < 16; ++s2) {
+      const int cc = 4 * s2 + q;
+      if (cc > c) a[s2] -= x * T[cc][c];
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) blk[(int64_t)r * ld + 4 * sl + q] = a[sl];
+}
+
+// invL[j] = inverse of the lower-triangular diagonal block L_jj, all blocks in one launch
+// (needed only by the backward substitution).  One column per 4 lanes, no barrier in the
+// column loop: lane q writes and re-reads exactly the entries Z[i][col] with i % 4 == q.
+__global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict__ aug, int ld,
+                                                        double* __restrict__ invL_all) {
+  __shared__ double T[CHB][CHB + 1];
+  __shared__ double Z[CHB][CHB + 1];
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x;
+  const double* blk = aug + ((int64_t)j * CHB) * ld + (int64_t)j * CHB;
+  for (int idx = tid; idx < CHB * CHB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    T[r][c] = (c <= r) ? blk[(int64_t)r * ld + c] : 0.0;
+    Z[r][c] = 0.0;
+  }
+  __syncthreads();
+  const int col = tid >> 2, q = tid & 3;
+  for (int i = col; i < CHB; ++i) {
+    double s = 0.0;
+    for (int jj = col + ((q - col) & 3); jj < i; jj += 4) s += T[i][jj] * Z[jj][col];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const double z = (i == col) ? 1.0 / T[i][i] : -s / T[i][i];
+    if ((i & 3) == q) Z[i][col] = z;
+  }
+  __syncthreads();
+  double* out = invL_all + (int64_t)j * CHB * CHB;
+  for (int idx = tid; idx < CHB * CHB; idx += 256) out[idx] = Z[idx >> 6][idx & 63];
+}
+
+// Trailing update  C[r][c] -= sum_{kk < K} P[r][kk] P[c][kk]  with P the K panel columns that
+// start at column pc0, on the lower 128x128 tiles of the region that starts at row/column o0
+// (a multiple of 64).  4 waves as 2x2, each 64x64 (16 accumulators that start as the C tile,
+// the row operand is negated, so the result is stored without a read-modify-write tail).
+// The panel rows of the tile are staged k-major through LDS in chunks of 16 columns, the next
+// chunk travelling in registers while the current one is multiplied.
+// Tile order: 4x4 super-tiles; blocks b, b+8, b+16, ... (the blocks that share an XCD under
+// round-robin dispatch) walk the 16 tiles of one super-tile, so its 2 x 4 x 128 panel rows
+// (1 MiB) are fetched into that XCD's L2 once per super-tile.  Placement affects speed only.
+#define SYK 16
+#define SYS 4
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ aug, int ld, int pc0, int K, int o0,
+                                                            int nrows, int ncols, int nst_rows) {
+  __shared__ double As[SYK][129];
+  __shared__ double Bs[SYK][129];
+  const int b = blockIdx.x;
+  const int st = (b / (8 * SYS * SYS)) * 8 + (b & 7);        // super-tile (lower-triangular enumeration)
+  const int within = (b >> 3) & (SYS * SYS - 1);
+  int si = 0, rem = st;
+  while (rem > si) {
+    rem -= si + 1;
+    ++si;
+  }
+  const int sk_ = rem;
+  if (si >= nst_rows) return;
+  const int ti = si * SYS + (within & (SYS - 1)), tk = sk_ * SYS + (within / SYS);
+  const int r0 = o0 + ti * 128, c0 = o0 + tk * 128;
+  if (ti < tk || r0 >= nrows || c0 >= ncols) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int srow = tid >> 1, sk = (tid & 1) * 8;
+  // rows past the end are clamped, not predicated (a load under a per-element branch is
+  // waited for one by one); what they feed is never stored.
+  const double* Ap = aug + (int64_t)min(r0 + srow, nrows - 1) * ld + pc0 + sk;
+  const double* Bp = aug + (int64_t)min(c0 + srow, ncols - 1) * ld + pc0 + sk;
+  double pa[8], pb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pa[e] = -Ap[e];
+    pb[e] = Bp[e];
+  }
+  d4 acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = min(r0 + wr * 64 + u * 16 + kq + 4 * t, nrows - 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int col = min(c0 + wc * 64 + v * 16 + li, ncols - 1);
+        acc[u][v][t] = aug[(int64_t)row * ld + col];
+      }
+    }
+  for (int kc = 0; kc < K; kc += SYK) {
+    if (kc) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      As[sk + e][srow] = pa[e];
+      Bs[sk + e][srow] = pb[e];
+    }
+    __syncthreads();
+    if (kc + SYK < K) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pa[e] = -Ap[kc + SYK + e];
+        pb[e] = Bp[kc + SYK + e];
+      }
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < SYK; k0 += 4) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        af[u] = As[k0 + kq][wr * 64 + u * 16 + li];
+        bf[u] = Bs[k0 + kq][wc * 64 + u * 16 + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = MFMA_F64(af[u], bf[v], acc[u][v]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = r0 + wr * 64 + u * 16 + kq + 4 * t;
+      if (row < nrows) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int col = c0 + wc * 64 + v * 16 + li;
+          if (col < ncols) aug[(int64_t)row * ld + col] = acc[u][v][t];
+        }
+      }
+    }
+}
+
+// One step of x = L^-T y: x_j = invL_jj^T y_j (every workgroup recomputes it, workgroup 0
+// stores it), then y_k -= L_jk^T x_j for block k = blockIdx.x < j.  y is the first row of the
+// extra block row of `aug`.  256 threads: 64 columns x 4 row groups, partial sums through LDS.
+__global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug, int ld, int nb, int j,
+                                                        const double* __restrict__ invL_all, double* __restrict__ x,
+                                                        int n) {
+  __shared__ double part[4][CHB];
+  __shared__ double xs[CHB];
+  double* y = aug + ((int64_t)nb * CHB) * ld;
+  const double* invL = invL_all + (int64_t)j * CHB * CHB;
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double acc = 0.0;
+#pragma unroll 4
+  for (int r = g * 16; r < g * 16 + 16; ++r)
+    if (r >= c) acc += invL[r * CHB + c] * y[j * CHB + r];
+  part[g][c] = acc;
+  __syncthreads();
+  if (g == 0) {
+    const double v = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    xs[c] = v;
+    if (blockIdx.x == 0 && j * CHB + c < n) x[j * CHB + c] = v;
+  }
+  __syncthreads();
+  const int k = blockIdx.x;
+  if (k < j) {
+    const double* Ljk = aug + ((int64_t)j * CHB) * ld + (int64_t)k * CHB;
+    double s = 0.0;
+#pragma unroll 4
+    for (int r = g * 16; r < g * 16 + 16; ++r) s += Ljk[(int64_t)r * ld + c] * xs[r];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0) y[k * CHB + c] -= part[0][c] + part[1][c] + part[2][c] + part[3][c];
+  }
+}
+
+// Gram expansion straight into the Cholesky storage: lower triangle of A/scale + ridge*I,
+// identity on the padded diagonal, zero elsewhere in the padded rows.
+__global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __restrict__ G, int rl, int p, int rr,
+                                                                 int sym, int NX, int NRpad,
+                                                                 const double* __restrict__ scale, double ridge,
+                                                                 double* __restrict__ A, int ld) {
+  const int D = rl * p * rr;
+  const int row = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col > row || col >= ld) return;
+  double v;
+  if (row >= D) {
+    v = (row == col) ? 1.0 : 0.0;
+  } else {
+    const int r = row % rr, lp = row / rr, pp = lp % p, l = lp / p;
+    const int t = col % rr, mq = col / rr, q = mq % p, m = mq / p;
+    const int a = sym ? tri_index(min(l, m), max(l, m), rl) : l * rl + m;
+    const int b = tri_index(min(pp, q), max(pp, q), p);
+    const int c = tri_index(min(r, t), max(r, t), rr);
+    v = G[((int64_t)a * NX + b) * NRpad + c];
+    if (scale) v = v / scale[0];
+    if (row == col) v += ridge;
+  }
+  A[(int64_t)row * ld + col] = v;
+}
+
 // Event pairs around the Gram kernel (diagnostic; armed by ttk_gram_timing).
 static const int kTimingPool = 512;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
@@ -735,29 +1126,34 @@ int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left)
   if (S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const GramDims d = gram_dims(S, C, rl, p, rr, sym_left);
   if (d.CH < 4) return TTK_EINVAL;
-  return (int64_t)(1 + (d.nslabs > 1 ? d.nslabs : 0)) * d.gsize * (int64_t)sizeof(double);
+  const int64_t W = 2 * (int64_t)C * rl + d.NX + rr + 1;
+  return ((int64_t)(1 + (d.nslabs > 1 ? d.nslabs : 0)) * d.gsize + S * W) * (int64_t)sizeof(double);
 }
 
-int ttk_gram_f64(const double* L, const double* HL, const double* X, const double* R, int64_t S, int C, int rl, int p,
+int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R, int64_t S, int C, int rl, int p,
                  int rr, int sym_left, void* ws, int64_t ws_bytes, void* stream) {
-  if (!L || !HL || !X || !R || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  if (!L || !H || !X || !R || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const GramDims d = gram_dims(S, C, rl, p, rr, sym_left);
   if (d.CH < 4) return TTK_EINVAL;
   if (ws_bytes < ttk_gram_ws_bytes(S, C, rl, p, rr, sym_left)) return TTK_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* G = (double*)ws;
   double* partial = d.nslabs > 1 ? G + d.gsize : G;
-  const size_t lds = (size_t)d.CH * (2 * C * rl + p + rr) * sizeof(double);
+  double* F = G + (int64_t)(1 + (d.nslabs > 1 ? d.nslabs : 0)) * d.gsize;
+  const int64_t W = 2 * (int64_t)C * rl + d.NX + rr + 1;
+  hipLaunchKernelGGL(gram_pack_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, st, L, H, X, R, S, C, rl, p,
+                     rr, F);
+  const size_t lds = (size_t)d.CH * W * sizeof(double);
   const unsigned grid = (unsigned)d.ngroups * (unsigned)d.nslabs;
   const bool timed = g_ev_armed && g_ev_count < kTimingPool;
-  if (timed) hipEventRecord(g_ev_start[g_ev_count], st);
+  if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
   if (C == 1)
-    hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds, st, L, HL, X, R, S, C, rl, p, rr, sym_left, d,
-                       partial);
+    hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds, st, (const double*)F, S, C, rl, p, rr, sym_left,
+                       d, partial);
   else
-    hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds, st, L, HL, X, R, S, C, rl, p, rr, sym_left, d,
-                       partial);
-  if (timed) hipEventRecord(g_ev_stop[g_ev_count++], st);
+    hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds, st, (const double*)F, S, C, rl, p, rr, sym_left,
+                       d, partial);
+  if (timed) (void)hipEventRecord(g_ev_stop[g_ev_count++], st);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 1) {
@@ -783,6 +1179,61 @@ int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, con
   const int D = rl * p * rr;
   hipLaunchKernelGGL(gram_expand_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)D), dim3(256), 0,
                      (hipStream_t)stream, (const double*)ws, rl, p, rr, sym_left, d.NX, d.NRpad, scale, ridge, A_out);
+  return ttk_launch_status();
+}
+
+int64_t ttk_chol_ws_bytes(int n) {
+  if (n < 1) return TTK_EINVAL;
+  const int64_t nb = (n + CHB - 1) / CHB;
+  return ((nb + 1) * CHB * nb * CHB + nb * CHB * CHB) * (int64_t)sizeof(double) + 256;
+}
+
+int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
+                         const double* b, const double* w, void* chol_ws, void* stream) {
+  if (!gram_ws || !b || !chol_ws || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const GramDims d = gram_dims(1, 1, rl, p, rr, sym_left);
+  const int n = rl * p * rr;
+  const int nb = (n + CHB - 1) / CHB;
+  const int ld = nb * CHB;
+  double* aug = (double*)chol_ws;
+  hipLaunchKernelGGL(gram_expand_lower_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)ld), dim3(256), 0, st,
+                     (const double*)gram_ws, rl, p, rr, sym_left, d.NX, d.NRpad, scale, ridge, aug, ld);
+  if (hipMemsetAsync(aug + (int64_t)ld * ld, 0, (size_t)CHB * ld * sizeof(double), st) != hipSuccess) return TTK_ELAUNCH;
+  hipLaunchKernelGGL(solve_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, w, scale, ridge,
+                     aug + (int64_t)ld * ld, (int64_t)n);
+  return ttk_launch_status();
+}
+
+int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
+  if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (n + CHB - 1) / CHB;
+  const int ld = nb * CHB;
+  const int nbr = nb + 1;
+  const int nrows = nbr * CHB, ncols = ld;
+  double* aug = (double*)chol_ws;
+  double* invL = aug + (int64_t)nbr * CHB * ld;
+  if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return TTK_ELAUNCH;
+  for (int j = 0; j < nb; ++j) {
+    // odd panels first absorb the previous panel's update of their own block column
+    hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info);
+    if ((j & 1) && j + 1 < nb) {
+      // panels j-1 and j together (K = 128) onto everything right of column j
+      const int o0 = (j + 1) * CHB;
+      const int trows = (nrows - o0 + 127) / 128;
+      const int nst_rows = (trows + SYS - 1) / SYS;
+      const int nst = nst_rows * (nst_rows + 1) / 2;
+      const unsigned grid = (unsigned)((nst + 7) / 8) * 8 * SYS * SYS;
+      hipLaunchKernelGGL(chol_syrk_kernel, dim3(grid), dim3(256), 0, st, aug, ld, (j - 1) * CHB, 2 * CHB, o0, nrows,
+                         ncols, nst_rows);
+    }
+  }
+  hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, invL);
+  int rc = ttk_launch_status();
+  if (rc != TTK_OK) return rc;
+  for (int j = nb - 1; j >= 0; --j)
+    hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(j > 0 ? j : 1)), dim3(256), 0, st, aug, ld, nb, j, invL, x, n);
   return ttk_launch_status();
 }
 

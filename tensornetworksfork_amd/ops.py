@@ -130,13 +130,13 @@ class GramWorkspace:
         return self.buf[:self.gsize]
 
 
-def gram(L, HL, X, R, sym=True, ws=None):
-    """Compressed Gram of the local normal equations -> GramWorkspace."""
+def gram(L, H, X, R, sym=True, ws=None):
+    """Compressed Gram of the local normal equations (H = per-sample Hessian (S,C,C)) -> GramWorkspace."""
     S, C, rl = L.shape
     p, rr = X.shape[1], R.shape[1]
     if ws is None or ws.dims != (S, C, rl, p, rr, int(bool(sym))):
         ws = GramWorkspace(S, C, rl, p, rr, sym, L.device)
-    rc = _lib.lib().ttk_gram_f64(_chk(L, "L"), _chk(HL, "HL", (S, C, rl)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
+    rc = _lib.lib().ttk_gram_f64(_chk(L, "L"), _chk(H, "H", (S, C, C)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
                                  S, C, rl, p, rr, int(bool(sym)), ws.buf.data_ptr(), ws.nbytes, _stream(L))
     _lib.check(rc, "ttk_gram_f64")
     return ws
@@ -212,6 +212,34 @@ def solve_rhs(b, w=None, scale=None, ridge=0.0):
                                       _stream(b))
     _lib.check(rc, "ttk_solve_rhs_f64")
     return out
+
+
+_chol_ws = {}
+
+
+def chol_solve_gram(ws, b, w=None, scale=None, ridge=0.0):
+    """x = -(A/scale + ridge I)^-1 (b/scale + ridge w) by the blocked MFMA Cholesky, with A taken
+    from a compressed Gram workspace.  Returns (x (D,), info) with info a device int32 scalar:
+    0, or the order of the first non-positive pivot."""
+    _, _, rl, p, rr, sym = ws.dims
+    D = rl * p * rr
+    nbytes = int(_lib.lib().ttk_chol_ws_bytes(D))
+    key = (ws.buf.device, D)
+    cw = _chol_ws.get(key)
+    if cw is None:
+        _chol_ws.clear()
+        cw = torch.empty((nbytes + 7) // 8, dtype=F64, device=ws.buf.device)
+        _chol_ws[key] = cw
+    st = _stream(ws.buf)
+    rc = _lib.lib().ttk_chol_prepare_f64(ws.buf.data_ptr(), rl, p, rr, sym, None if scale is None else _chk(scale, "scale"),
+                                         float(ridge), _chk(b, "b"), None if w is None else _chk(w, "w"),
+                                         cw.data_ptr(), st)
+    _lib.check(rc, "ttk_chol_prepare_f64")
+    x = torch.empty((D,), dtype=F64, device=ws.buf.device)
+    info = torch.empty((), dtype=torch.int32, device=ws.buf.device)
+    rc = _lib.lib().ttk_chol_solve_f64(cw.data_ptr(), D, x.data_ptr(), info.data_ptr(), st)
+    _lib.check(rc, "ttk_chol_solve_f64")
+    return x, info
 
 
 def dot(x, y):

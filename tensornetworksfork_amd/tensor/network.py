@@ -367,7 +367,7 @@ class TensorNetwork:
         ws = self._gram_ws.get(key)
         if ws is None:
             self._gram_ws.clear()
-        ws = ops.gram(L, ops.hess_left(H, L), X, R, sym=sym, ws=ws)
+        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
         self._gram_ws[key] = ws
         return ws
 
@@ -460,18 +460,23 @@ class TensorNetwork:
             self._shard.allreduce_sum_(ws.compressed)
             self._shard.allreduce_sum_(b)
         scale = ops.gram_scale(ws)
-        D = st.rl * st.p * st.rr
-        buf = self._abuf.get(D)
-        if buf is None:
-            self._abuf.clear()
-            buf = torch.empty((D, D), dtype=torch.float64, device=L.device)
-            self._abuf[D] = buf
-        A_f = ops.gram_expand(ws, scale=scale, ridge=2 * eps_ if ridged else 0.0, out=buf)
-        rhs = ops.solve_rhs(b, core if ridged else None, scale, 2 * eps_ if ridged else 0.0)
+        ridge = 2 * eps_ if ridged else 0.0
         if m in ('exact', 'ridge_exact'):
-            x = torch.linalg.solve(A_f, rhs)
+            D = st.rl * st.p * st.rr
+            buf = self._abuf.get(D)
+            if buf is None:
+                self._abuf.clear()
+                buf = torch.empty((D, D), dtype=torch.float64, device=L.device)
+                self._abuf[D] = buf
+            A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=buf)
+            x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
         else:
-            x = _cholesky_solve(A_f, rhs)
+            x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
+            bad = int(info.item())
+            if bad != 0:
+                raise torch.linalg.LinAlgError(
+                    "linalg.cholesky: The factorization could not be completed because the input is not "
+                    f"positive-definite (the leading minor of order {bad} is not positive-definite).")
         node.update_node(self._from_canon(k, x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm,
                          max_norm=max_norm)
         return None if total is None else total.item()

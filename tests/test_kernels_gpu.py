@@ -78,8 +78,7 @@ def test_gram_rhs_matvec(S, C, rl, p, rr):
     for sym, H in ((True, Hsym), (False, Hh)):
         A_r, b_r = O.local_gram_rhs(L, X, R, g, H)
         Ld, Xd, Rd, Hd = L.to(dev), X.to(dev), R.to(dev), H.contiguous().to(dev)
-        HL = ops.hess_left(Hd, Ld)
-        ws = ops.gram(Ld, HL, Xd, Rd, sym=sym)
+        ws = ops.gram(Ld, Hd, Xd, Rd, sym=sym)
         A = ops.gram_expand(ws)
         D = rl * p * rr
         assert G.rel_err(A, A_r.reshape(D, D)) < TOL, ("gram", sym)
@@ -121,12 +120,40 @@ def test_gram_large_slabbed():
     H = torch.full((S, 1, 1), 2.0, dtype=torch.float64)
     A_r, _ = O.local_gram_rhs(L, X, R, torch.zeros(S, 1, dtype=torch.float64), H)
     Ld, Xd, Rd, Hd = L.to(dev), X.to(dev), R.to(dev), H.to(dev)
-    A = ops.gram_expand(ops.gram(Ld, ops.hess_left(Hd, Ld), Xd, Rd, sym=True))
+    A = ops.gram_expand(ops.gram(Ld, Hd, Xd, Rd, sym=True))
     D = rl * p * rr
     assert G.rel_err(A, A_r.reshape(D, D)) < TOL
     h = S // 2
-    A1 = ops.gram_expand(ops.gram(Ld[:h].contiguous(), ops.hess_left(Hd[:h].contiguous(), Ld[:h].contiguous()),
-                                  Xd[:h].contiguous(), Rd[:h].contiguous(), sym=True))
-    A2 = ops.gram_expand(ops.gram(Ld[h:].contiguous(), ops.hess_left(Hd[h:].contiguous(), Ld[h:].contiguous()),
-                                  Xd[h:].contiguous(), Rd[h:].contiguous(), sym=True))
+    A1 = ops.gram_expand(ops.gram(Ld[:h].contiguous(), Hd[:h].contiguous(), Xd[:h].contiguous(), Rd[:h].contiguous(),
+                                  sym=True))
+    A2 = ops.gram_expand(ops.gram(Ld[h:].contiguous(), Hd[h:].contiguous(), Xd[h:].contiguous(), Rd[h:].contiguous(),
+                                  sym=True))
     assert G.rel_err(A1 + A2, A) < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", [(96, 1, 4, 3, 4), (400, 1, 8, 3, 8), (700, 2, 7, 5, 9), (900, 1, 16, 6, 16),
+                                         (64, 1, 4, 3, 1), (50, 1, 1, 5, 4)])
+def test_cholesky_solve(S, C, rl, p, rr):
+    """Blocked MFMA Cholesky (with the RHS as an extra block row) against a CPU LAPACK solve of
+    the same scaled, ridge-shifted system; orders below, at and above multiples of the 64 block."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    L, X, R = _rand((S, C, rl), 41), _rand((S, p), 42), _rand((S, rr), 43)
+    g = _rand((S, C), 44)
+    Hh = _rand((S, C, C), 45)
+    H = (Hh @ Hh.transpose(1, 2) + 0.1 * torch.eye(C, dtype=torch.float64)).contiguous()
+    w = _rand((rl, p, rr), 46)
+    A_r, b_r = O.local_gram_rhs(L, X, R, g, H)
+    D = rl * p * rr
+    Ld, Xd, Rd, Hd = L.to(dev), X.to(dev), R.to(dev), H.to(dev)
+    ws = ops.gram(Ld, Hd, Xd, Rd, sym=True)
+    b = ops.rhs(Ld, Xd, Rd, g.to(dev))
+    scale = ops.gram_scale(ws)
+    for ridge in (2.0, 0.02):
+        x, info = ops.chol_solve_gram(ws, b, w.to(dev), scale, ridge)
+        assert int(info.item()) == 0
+        x_r = O.solve_system(A_r, b_r, w, 'ridge_cholesky', ridge / 2)
+        assert G.rel_err(x, x_r.reshape(-1)) < 1e-8, (D, ridge)
+    x, info = ops.chol_solve_gram(ws, b, w.to(dev), scale, -10.0)
+    assert int(info.item()) == 1

@@ -30,11 +30,10 @@ def timeit(name, fn, n=10, flops=None, bytes_=None):
     print(f"{name:28s} {ms:9.4f} ms{extra}", flush=True)
     return ms
 
-HL = ops.hess_left(H, L)
-ws = ops.gram(L, HL, X, R, sym=True)
+ws = ops.gram(L, H, X, R, sym=True)
 gd_flops = 2.0 * S * 528 * 21 * 528
 timeit("hess_left", lambda: ops.hess_left(H, L))
-timeit("gram (compressed)", lambda: ops.gram(L, HL, X, R, sym=True, ws=ws), n=5, flops=gd_flops)
+timeit("gram (compressed)", lambda: ops.gram(L, H, X, R, sym=True, ws=ws), n=5, flops=gd_flops)
 scale = ops.gram_scale(ws)
 A = torch.empty(D, D, dtype=torch.float64, device=dev)
 timeit("gram_scale", lambda: ops.gram_scale(ws))
@@ -45,6 +44,9 @@ timeit("env_step_right", lambda: ops.env_step_right(R, X, core), flops=2.0 * S *
 v = torch.rand(rl, p, rr, dtype=torch.float64, device=dev)
 timeit("matvec (jvp+rhs)", lambda: ops.matvec(L, X, R, H, v), flops=4.0 * S * D)
 timeit("predict", lambda: ops.predict(L, R))
+w = torch.rand(rl, p, rr, dtype=torch.float64, device=dev)
+bb = ops.rhs(L, X, R, g)
+timeit("chol_solve_gram (own)", lambda: ops.chol_solve_gram(ws, bb, w, scale, 1.0), n=5, flops=D ** 3 / 3)
 timeit("torch cholesky 6144", lambda: torch.linalg.cholesky(A), n=3, flops=D ** 3 / 3)
 Lc = torch.linalg.cholesky(A)
 b = torch.rand(D, 1, dtype=torch.float64, device=dev)

@@ -1,0 +1,21 @@
+"""Scratch: run the Cholesky solve a few times for rocprofv3."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tensornetworksfork_amd import ops
+dev = torch.device("cuda:0")
+S, C, rl, p, rr = 54000, 1, 32, 6, 32
+torch.manual_seed(0)
+L = torch.rand(S, C, rl, dtype=torch.float64, device=dev) - 0.5
+X = torch.rand(S, p, dtype=torch.float64, device=dev) - 0.5
+R = torch.rand(S, rr, dtype=torch.float64, device=dev) - 0.5
+H = torch.full((S, 1, 1), 2.0, dtype=torch.float64, device=dev)
+g = torch.rand(S, C, dtype=torch.float64, device=dev)
+w = torch.rand(rl, p, rr, dtype=torch.float64, device=dev)
+ws = ops.gram(L, H, X, R, sym=True)
+b = ops.rhs(L, X, R, g)
+scale = ops.gram_scale(ws)
+for _ in range(4):
+    x, info = ops.chol_solve_gram(ws, b, w, scale, 1.0)
+torch.cuda.synchronize()
+print(int(info.item()), x.norm().item())
