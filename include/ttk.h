@@ -128,6 +128,13 @@ int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_lef
                          const double* b, const double* w, void* chol_ws, void* stream);
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream);
 
+/* Reduced Householder QR of a row-major (m,n) matrix in one workgroup, LAPACK sign
+ * conventions: A = Q R, Q (m,k), R (k,n), k = min(m,n).  Replaces torch.linalg.qr in
+ * node_orthonormalize_left/right (tensor/network.py:644,686).  Needs ttk_qr_lds_bytes(m,n)
+ * <= 150 KiB of LDS (returns TTK_EINVAL otherwise: the caller keeps its library QR). */
+int64_t ttk_qr_lds_bytes(int m, int n);
+int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream);
+
 /* Krylov vector kernels with wavefront-shuffle reductions (lanczos_solver,
  * tensor/network.py:796-824): out[0] = <x,y>;  y += a[0]*x  (a on device);
  * Both leave results on the device so that an iteration needs no host sync. */

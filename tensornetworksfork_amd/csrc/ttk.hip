@@ -264,9 +264,10 @@ __global__ __launch_bounds__(256) void hess_left_kernel(const double* __restrict
 // A is invariant under l<->m, p<->q, r<->t separately, so G holds every distinct entry
 // once: for rl=rr=32, p=6 that is 528*21*528 numbers instead of 6144^2 (6.4x fewer FLOPs).
 // GEMM view: rows a, columns (b,c), contraction over samples.  One wave owns a 48x48
-// (a,c) tile of one b (3x3 MFMA tiles, 9 independent accumulators); the 4 waves of a
-// workgroup take 4 consecutive tiles and share the LDS-staged factor rows of a sample
-// chunk.  blockIdx.x % nslabs selects the sample slab, so workgroups that share an XCD
+// (a,c) tile of two consecutive b (2 x 3x3 MFMA tiles, 18 independent accumulators: the
+// P and RR operand products are shared by both b, which halves the fp64 multiplies, LDS
+// reads and address arithmetic per MFMA); the 4 waves of a workgroup take 4 consecutive
+// tiles and share the LDS-staged factor rows of a sample chunk.  blockIdx.x % nslabs selects the sample slab, so workgroups that share an XCD
 // (blockIdx % 8) stream the same slab through that XCD's L2.  Each (tile, slab) result
 // goes to its own slab of `partial`; a second kernel sums slabs in fixed order.
 // ---------------------------------------------------------------------------------------
@@ -285,7 +286,7 @@ __host__ __device__ __forceinline__ int tri_index(int i, int j, int n) {  // req
 }
 
 struct GramDims {
-  int MP, MPpad, NX, NR, NRpad, ntm, ntn, ntiles, ngroups, nslabs, CH;
+  int MP, MPpad, NX, NR, NRpad, ntm, ntn, nbp, ntiles, ngroups, nslabs, CH;
   int64_t slab_len, gsize;
 };
 
@@ -298,16 +299,34 @@ static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym) {
   d.NRpad = round_up(d.NR, 48);
   d.ntm = d.MPpad / 48;
   d.ntn = d.NRpad / 48;
-  d.ntiles = d.NX * d.ntm * d.ntn;
+  d.nbp = (d.NX + 1) / 2;              // a wave tile carries two (p,q) pairs
+  d.ntiles = d.nbp * d.ntm * d.ntn;
   d.ngroups = (d.ntiles + 3) / 4;
   d.gsize = (int64_t)d.MPpad * d.NX * d.NRpad;
-  int want = (1024 + d.ngroups - 1) / d.ngroups;
+  // sample slabs: enough workgroups to fill 256 CUs x 2 several times over, a multiple of 8 for
+  // large S (one slab per XCD under round-robin dispatch), chosen to keep the last wave of
+  // workgroups reasonably full
   int64_t cap = S / 512;
   if (cap < 1) cap = 1;
-  if (want > cap) want = (int)cap;
-  if (want > 64) want = 64;
-  if (want >= 5 || S >= 8 * 2048) want = round_up(want < 8 ? 8 : want, 8);
-  d.nslabs = want < 1 ? 1 : want;
+  int best = 1;
+  if (S >= 8 * 2048) {
+    double best_cost = 1e30;
+    for (int ns = 8; ns <= 32 && ns <= cap; ns += 8) {
+      const double rounds = (double)d.ngroups * ns / 512.0;
+      const double full = rounds < 1.0 ? 1.0 : (double)(int64_t)(rounds + 0.999999);
+      const double cost = full / rounds + 0.004 * ns;   // tail waste + price of one more partial copy
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = ns;
+      }
+    }
+  } else {
+    int want = (1024 + d.ngroups - 1) / d.ngroups;
+    if (want > cap) want = (int)cap;
+    if (want > 64) want = 64;
+    best = want < 1 ? 1 : want;
+  }
+  d.nslabs = best;
   d.slab_len = round_up64((S + d.nslabs - 1) / d.nslabs, 4);
   // chunk of samples staged in LDS: (2*C*rl + p + rr) doubles per sample, <= 56 KiB
   const int width = 2 * C * rl + d.NX + rr + 1;
@@ -378,15 +397,17 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   const int group = blockIdx.x / gd.nslabs;
   const int tile = group * 4 + wave;
   const bool active = tile < gd.ntiles;
-  int b = 0, tm = 0, tn = 0;
+  int bp = 0, tm = 0, tn = 0;
   if (active) {
-    b = tile / (gd.ntm * gd.ntn);
-    const int rem = tile - b * (gd.ntm * gd.ntn);
+    bp = tile / (gd.ntm * gd.ntn);
+    const int rem = tile - bp * (gd.ntm * gd.ntn);
     tm = rem / gd.ntn;
     tn = rem - tm * gd.ntn;
   }
+  const int b0 = 2 * bp, b1 = 2 * bp + 1;
   // element offsets inside a sample row of the chunk image; W - 1 is the zero column
-  const int oX = 2 * CW + b;
+  const int oX0 = 2 * CW + b0;
+  const int oX1 = b1 < gd.NX ? 2 * CW + b1 : W - 1;
   int oH[3], oL[3], oR1[3], oR2[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -414,11 +435,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
       oR1[u] = oR2[u] = W - 1;
     }
   }
-  d4 acc[3][3];
+  d4 acc[2][3][3];
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int v = 0; v < 3; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) acc[h][u][v] = d4{0.0, 0.0, 0.0, 0.0};
 
   const int64_t s_begin = (int64_t)slab * gd.slab_len;
   int64_t s_end = s_begin + gd.slab_len;
@@ -441,8 +464,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
       const int steps = (int)((nvalid + 3) >> 2);
       for (int ks = 0; ks < steps; ++ks) {
         const double* row = smem + (ks * 4 + kq) * W;
-        const double xx = row[oX];
-        double aop[3], bop[3];
+        const double xx0 = row[oX0], xx1 = row[oX1];
+        double aop0[3], aop1[3], bop[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           double pa;
@@ -453,13 +476,17 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
             if (oL[u] != W - 1)
               for (int d = 0; d < C; ++d) pa += row[oH[u] + d * rl] * row[oL[u] + d * rl];
           }
-          aop[u] = pa * xx;
+          aop0[u] = pa * xx0;
+          aop1[u] = pa * xx1;
           bop[u] = row[oR1[u]] * row[oR2[u]];
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
-          for (int v = 0; v < 3; ++v) acc[u][v] = MFMA_F64(aop[u], bop[v], acc[u][v]);
+          for (int v = 0; v < 3; ++v) {
+            acc[0][u][v] = MFMA_F64(aop0[u], bop[v], acc[0][u][v]);
+            acc[1][u][v] = MFMA_F64(aop1[u], bop[v], acc[1][u][v]);
+          }
       }
     }
   }
@@ -473,7 +500,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
         for (int t = 0; t < 4; ++t) {
           const int a = tm * 48 + u * 16 + kq + 4 * t;
           const int c = tn * 48 + v * 16 + i;
-          dst[((int64_t)a * gd.NX + b) * gd.NRpad + c] = acc[u][v][t];
+          dst[((int64_t)a * gd.NX + b0) * gd.NRpad + c] = acc[0][u][v][t];
+          if (b1 < gd.NX) dst[((int64_t)a * gd.NX + b1) * gd.NRpad + c] = acc[1][u][v][t];
         }
   }
 }
@@ -1037,6 +1065,109 @@ __global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __
   A[(int64_t)row * ld + col] = v;
 }
 
+// ---------------------------------------------------------------------------------------
+// Householder QR of a tall-skinny core matrix (m x n, m*n small) in one workgroup, LAPACK
+// conventions (dgeqr2 + dorg2r): beta = -sign(alpha) * ||x||, v = x / (alpha - beta) with
+// v[0] = 1, tau = (beta - alpha) / beta, R's diagonal = beta; Q = H_1 ... H_k applied to the
+// first k columns of the identity, k = min(m, n).  Same signs as torch.linalg.qr on the CPU,
+// which is what fixes the gauge of the orthonormalised cores.
+// LDS: A (m x n, column-major, stride m+1) and tau; one column of reflector work per step.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain, int m, int n, double* __restrict__ Q,
+                                                  double* __restrict__ Rout) {
+  extern __shared__ double smem[];
+  const int k = min(m, n);
+  const int ldm = m + 1;
+  double* A = smem;                 // A[c * ldm + r]
+  double* tau = A + (size_t)n * ldm;
+  double* red = tau + k;            // 4 partial sums + broadcast slots
+  double* wv = red + 8;             // w[c] = v^T A[:,c], n entries
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int idx = tid; idx < m * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    A[c * ldm + r] = Ain[idx];
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    // ||x||^2 of A[j+1:, j]
+    double part = 0.0;
+    for (int r = j + 1 + tid; r < m; r += 256) part += A[j * ldm + r] * A[j * ldm + r];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const double xn2 = red[0] + red[1] + red[2] + red[3];
+      const double alpha = A[j * ldm + j];
+      double t = 0.0, beta = alpha, scale = 0.0;
+      if (xn2 != 0.0) {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        t = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      tau[j] = t;
+      red[4] = scale;
+      red[5] = beta;
+    }
+    __syncthreads();
+    const double scale = red[4], t = tau[j];
+    for (int r = j + 1 + tid; r < m; r += 256) A[j * ldm + r] *= scale;
+    __syncthreads();
+    // w[c] = v^T A[:, c] for c > j (v[j] = 1), one wave per column
+    for (int c = j + 1 + wave; c < n; c += 4) {
+      double acc = 0.0;
+      for (int r = j + 1 + lane; r < m; r += 64) acc += A[j * ldm + r] * A[c * ldm + r];
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) wv[c] = acc + A[c * ldm + j];
+    }
+    __syncthreads();
+    // A[:, c] -= tau * v * w[c]
+    const int ncol = n - j - 1, nrow = m - j;
+    for (int idx = tid; idx < ncol * nrow; idx += 256) {
+      const int c = j + 1 + idx / nrow, r = j + idx % nrow;
+      const double v = (r == j) ? 1.0 : A[j * ldm + r];
+      A[c * ldm + r] -= t * v * wv[c];
+    }
+    if (tid == 0) A[j * ldm + j] = red[5];
+    __syncthreads();
+  }
+  // R (k x n, upper triangular)
+  for (int idx = tid; idx < k * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    Rout[idx] = (r <= c) ? A[c * ldm + r] : 0.0;
+  }
+  __syncthreads();
+  // Q = H_1 ... H_k I[:, :k], built in place of the reflectors from the last one backwards
+  // (dorg2r): column j of the work array holds v_j below the diagonal.
+  double* Qw = wv + n;   // Qw[c * ldm + r], m x k
+  for (int idx = tid; idx < m * k; idx += 256) {
+    const int c = idx / m, r = idx - c * m;
+    Qw[c * ldm + r] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int j = k - 1; j >= 0; --j) {
+    const double t = tau[j];
+    for (int c = j + wave; c < k; c += 4) {
+      double acc = 0.0;
+      for (int r = j + 1 + lane; r < m; r += 64) acc += A[j * ldm + r] * Qw[c * ldm + r];
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) wv[c] = acc + Qw[c * ldm + j];
+    }
+    __syncthreads();
+    const int ncol = k - j, nrow = m - j;
+    for (int idx = tid; idx < ncol * nrow; idx += 256) {
+      const int c = j + idx / nrow, r = j + idx % nrow;
+      const double v = (r == j) ? 1.0 : A[j * ldm + r];
+      Qw[c * ldm + r] -= t * v * wv[c];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < m * k; idx += 256) {
+    const int r = idx / k, c = idx - r * k;
+    Q[idx] = Qw[c * ldm + r];
+  }
+}
+
 // Event pairs around the Gram kernel (diagnostic; armed by ttk_gram_timing).
 static const int kTimingPool = 512;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
@@ -1269,6 +1400,23 @@ int ttk_jvp_f64(const double* L, const double* X, const double* R, const double*
   int rc = env_step_launch(true, L, X, v, tmp, S * C, C, rl, p, rr, st);
   if (rc != TTK_OK) return rc;
   hipLaunchKernelGGL(jvp_finish_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, tmp, R, H, hu, S, C, rr);
+  return ttk_launch_status();
+}
+
+int64_t ttk_qr_lds_bytes(int m, int n) {
+  if (m < 1 || n < 1) return TTK_EINVAL;
+  const int64_t k = m < n ? m : n;
+  return ((int64_t)n * (m + 1) + k + 8 + n + k * (int64_t)(m + 1)) * (int64_t)sizeof(double);
+}
+
+int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream) {
+  if (!A || !Q || !R || m < 1 || n < 1) return TTK_EINVAL;
+  const int64_t lds = ttk_qr_lds_bytes(m, n);
+  if (lds > 150 * 1024) return TTK_EINVAL;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TTK_ELAUNCH;
+  hipLaunchKernelGGL(qr_kernel, dim3(1), dim3(256), (size_t)lds, (hipStream_t)stream, A, m, n, Q, R);
   return ttk_launch_status();
 }
 

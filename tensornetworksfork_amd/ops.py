@@ -242,6 +242,24 @@ def chol_solve_gram(ws, b, w=None, scale=None, ridge=0.0):
     return x, info
 
 
+QR_LDS_LIMIT = 150 * 1024
+
+
+def qr(A):
+    """Reduced QR (LAPACK signs) of a device matrix: one-workgroup HIP kernel when it fits in
+    LDS, torch.linalg.qr (rocSOLVER) otherwise or for non-float64 / CPU input."""
+    m, n = A.shape
+    if (not A.is_cuda) or A.dtype != F64 or _lib.lib().ttk_qr_lds_bytes(m, n) > QR_LDS_LIMIT:
+        return torch.linalg.qr(A, mode='reduced')
+    A = A.contiguous()
+    k = min(m, n)
+    Q = torch.empty((m, k), dtype=F64, device=A.device)
+    R = torch.empty((k, n), dtype=F64, device=A.device)
+    rc = _lib.lib().ttk_qr_f64(A.data_ptr(), m, n, Q.data_ptr(), R.data_ptr(), _stream(A))
+    _lib.check(rc, "ttk_qr_f64")
+    return Q, R
+
+
 def dot(x, y):
     out = torch.empty((), dtype=F64, device=x.device)
     rc = _lib.lib().ttk_dot_f64(_chk(x, "x"), _chk(y, "y"), out.data_ptr(), x.numel(), _stream(x))

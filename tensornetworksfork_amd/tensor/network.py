@@ -629,7 +629,7 @@ class TensorNetwork:
         rest = [a for a in range(node.tensor.ndim) if a not in bond]
         perm = rest + bond
         P = node.tensor.permute(perm)
-        Q, Rm = torch.linalg.qr(P.flatten(0, len(rest) - 1), mode='reduced')
+        Q, Rm = ops.qr(P.flatten(0, len(rest) - 1))
         Q = Q.reshape(tuple(P.shape[:len(rest)]) + (Q.shape[-1],))
         node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))
         nxt = self.main_nodes[i + 1]
@@ -645,7 +645,7 @@ class TensorNetwork:
         rest = [a for a in range(node.tensor.ndim) if a not in bond]
         perm = rest + bond
         P = node.tensor.permute(perm)
-        Qr, Rr = torch.linalg.qr(torch.flip(P.flatten(0, len(rest) - 1), dims=[0, 1]), mode='reduced')
+        Qr, Rr = ops.qr(torch.flip(P.flatten(0, len(rest) - 1), dims=[0, 1]))
         Rm = torch.flip(Rr.T, dims=[0, 1])
         Q = torch.flip(Qr, dims=[0, 1]).reshape(tuple(P.shape[:len(rest)]) + (Qr.shape[-1],))
         node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))

@@ -157,3 +157,18 @@ def test_cholesky_solve(S, C, rl, p, rr):
         assert G.rel_err(x, x_r.reshape(-1)) < 1e-8, (D, ridge)
     x, info = ops.chol_solve_gram(ws, b, w.to(dev), scale, -10.0)
     assert int(info.item()) == 1
+
+
+@gpu
+@pytest.mark.parametrize("m,n", [(192, 32), (6, 6), (36, 32), (17, 32), (12, 4), (5, 1), (1, 3), (300, 48), (64, 64)])
+def test_qr_matches_lapack(m, n):
+    """One-workgroup Householder QR against torch.linalg.qr on the CPU (same sign convention)."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    A = _rand((m, n), 51)
+    Q, R = ops.qr(A.to(dev))
+    Qr, Rr = torch.linalg.qr(A, mode='reduced')
+    assert tuple(Q.shape) == tuple(Qr.shape) and tuple(R.shape) == tuple(Rr.shape)
+    assert G.rel_err(Q, Qr) < 1e-10
+    assert G.rel_err(R, Rr) < 1e-10
+    assert G.rel_err(Q.cpu() @ R.cpu(), A) < 1e-12
