@@ -922,16 +922,22 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
   __shared__ double As[SYK][129];
   __shared__ double Bs[SYK][129];
   const int b = blockIdx.x;
-  const int st = (b / (8 * SYS * SYS)) * 8 + (b & 7);        // super-tile (lower-triangular enumeration)
-  const int within = (b >> 3) & (SYS * SYS - 1);
-  int si = 0, rem = st;
-  while (rem > si) {
-    rem -= si + 1;
-    ++si;
+  int ti, tk;
+  if (nst_rows <= 0) {   // one tile column: blockIdx.x is the tile row
+    ti = b;
+    tk = 0;
+  } else {
+    const int st = (b / (8 * SYS * SYS)) * 8 + (b & 7);      // super-tile (lower-triangular enumeration)
+    const int within = (b >> 3) & (SYS * SYS - 1);
+    int si = 0, rem = st;
+    while (rem > si) {
+      rem -= si + 1;
+      ++si;
+    }
+    if (si >= nst_rows) return;
+    ti = si * SYS + (within & (SYS - 1));
+    tk = rem * SYS + (within / SYS);
   }
-  const int sk_ = rem;
-  if (si >= nst_rows) return;
-  const int ti = si * SYS + (within & (SYS - 1)), tk = sk_ * SYS + (within / SYS);
   const int r0 = o0 + ti * 128, c0 = o0 + tk * 128;
   if (ti < tk || r0 >= nrows || c0 >= ncols) return;
   const int tid = threadIdx.x;
@@ -1336,6 +1342,19 @@ int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_lef
   return ttk_launch_status();
 }
 
+static void chol_syrk_launch(hipStream_t st, double* aug, int ld, int pc0, int K, int o0, int nrows, int ncols) {
+  if (o0 >= ncols || o0 >= nrows) return;
+  const int trows = (nrows - o0 + 127) / 128;
+  if (ncols - o0 <= 128) {
+    hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)trows), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, 0);
+    return;
+  }
+  const int nst_rows = (trows + SYS - 1) / SYS;
+  const int nst = nst_rows * (nst_rows + 1) / 2;
+  const unsigned grid = (unsigned)((nst + 7) / 8) * 8 * SYS * SYS;
+  hipLaunchKernelGGL(chol_syrk_kernel, dim3(grid), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, nst_rows);
+}
+
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
   if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1346,19 +1365,14 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   double* aug = (double*)chol_ws;
   double* invL = aug + (int64_t)nbr * CHB * ld;
   if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return TTK_ELAUNCH;
+  // One stream.  (A look-ahead that factorises the next pair of panels on a second,
+  // high-priority stream beside the trailing update was measured and gained nothing: the
+  // panel workgroups queue behind resident trailing-update workgroups for CU space.)
   for (int j = 0; j < nb; ++j) {
     // odd panels first absorb the previous panel's update of their own block column
     hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info);
-    if ((j & 1) && j + 1 < nb) {
-      // panels j-1 and j together (K = 128) onto everything right of column j
-      const int o0 = (j + 1) * CHB;
-      const int trows = (nrows - o0 + 127) / 128;
-      const int nst_rows = (trows + SYS - 1) / SYS;
-      const int nst = nst_rows * (nst_rows + 1) / 2;
-      const unsigned grid = (unsigned)((nst + 7) / 8) * 8 * SYS * SYS;
-      hipLaunchKernelGGL(chol_syrk_kernel, dim3(grid), dim3(256), 0, st, aug, ld, (j - 1) * CHB, 2 * CHB, o0, nrows,
-                         ncols, nst_rows);
-    }
+    // panels j-1 and j together (K = 128) onto everything right of column j
+    if ((j & 1) && j + 1 < nb) chol_syrk_launch(st, aug, ld, (j - 1) * CHB, 2 * CHB, (j + 1) * CHB, nrows, ncols);
   }
   hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, invL);
   int rc = ttk_launch_status();
