@@ -30,23 +30,30 @@ extern "C" {
 
 int ttk_version(void);
 
-/* Left environment step  out[s,c,r] = sum_{l,p} E[s,c,l] core[l,p,r] X[s,p].
- * E (S,C,rl), X (S,p), core (rl,p,rr), out (S,C,rr).
+/* Left environment step  out[s,c,r] (+)= sum_{l,p} E[s,c,l] core[l,p,r] X[s,p].
+ * E (S,C,rl), X (S,p), core (rl,p,rr), out (S,C,rr).  accumulate != 0 adds to `out` (used to sum
+ * the conv-bond terms of a conv-featurised column, tensor/layers.py:839-872).
  * Replaces the pair of einsums issued by TensorNode.contract_with for one
  * column of compute_stacks('left') / left_update_stacks
  * (tensor/network.py:55-71,152-161; tensor/node.py:28-45). */
 int ttk_env_step_left_f64(const double* E, const double* X, const double* core, double* out,
-                          int64_t S, int C, int rl, int p, int rr, void* stream);
+                          int64_t S, int C, int rl, int p, int rr, int accumulate, void* stream);
 
 /* Right environment step  out[s,l] = sum_{p,r} core[l,p,r] X[s,p] R[s,r].
  * R (S,rr), X (S,p), core (rl,p,rr), out (S,rl).
  * compute_stacks('right') / right_update_stacks (tensor/network.py:55-71,163-172). */
 int ttk_env_step_right_f64(const double* R, const double* X, const double* core, double* out,
-                           int64_t S, int rl, int p, int rr, void* stream);
+                           int64_t S, int rl, int p, int rr, int accumulate, void* stream);
 
-/* Prediction  y[s,c] = sum_r L[s,c,r] R[s,r]; L (S,C,r), R (S,r), y (S,C).
+/* Prediction  y[s,c] (+)= sum_r L[s,c,r] R[s,r]; L (S,C,r), R (S,r), y (S,C).
  * Last contraction of TensorNetwork.forward (tensor/network.py:121-131). */
-int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int C, int r, void* stream);
+int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int C, int r, int accumulate, void* stream);
+
+/* Explicit Jacobian rows  J[s,c,(l,p,r)] (+)= L[s,c,l] X[s,p] R[s,r]  (S,C,rl*p*rr), the tensor
+ * compute_jacobian_stack materialises (tensor/network.py:101-113).  Only used where the local
+ * Jacobian is a SUM of such terms (conv bond > 0) and the Gram matrix is wanted. */
+int ttk_kr_rows_f64(const double* L, const double* X, const double* R, double* J, int64_t S, int C, int rl, int p, int rr,
+                    int accumulate, void* stream);
 
 /* Losses: per-sample value, gradient g (S,C) and Hessian H (S,C,C) w.r.t. the
  * model output.  kind 0: SquareBregFunction (tensor/bregman.py:9-23,34-52;
@@ -95,10 +102,10 @@ int ttk_gram_timing_read(double* ms_out, int max);
 /* Right-hand side / transposed Jacobian product
  *   b[l,p,r] = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]
  * (get_A_b / get_b, tensor/network.py:215,289; second einsum of the matrix-free
- * product, network.py:789).  b (rl,p,rr). */
+ * product, network.py:789).  b (rl,p,rr); accumulate != 0 adds to b. */
 int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr);
 int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b,
-                int64_t S, int C, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream);
+                int64_t S, int C, int rl, int p, int rr, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 
 /* Jacobian-vector product  u[s,c] = sum_{l,p,r} L[s,c,l] X[s,p] R[s,r] v[l,p,r]
  * followed by hu[s,d] = sum_c H[s,c,d] u[s,c]  (first einsum of the matrix-free

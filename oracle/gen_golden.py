@@ -300,3 +300,77 @@ if __name__ == "__main__":
 
     gen_qr("n5p4r6c1", 5, 4, 6, 1, 31)
     gen_qr("n4p3r4c3", 4, 3, 4, 3, 32)
+
+
+# ---------------------------------------------------------------- 6. conv-featurised TT
+def _conv_layer(N, r, patches, pixels, C, CB, seed):
+    torch.manual_seed(seed)
+    return layers.TensorConvolutionTrainLayer(N, r, patches, pixels, output_shape=C, convolution_bond=CB)
+
+
+def _snap_train(tn):
+    return [n.tensor.detach().clone() for n in tn.train_nodes]
+
+
+def gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind="xe"):
+    layer = _conv_layer(N, r, patches, pixels, C, CB, seed)
+    tn = layer.tensor_network
+    g = torch.Generator().manual_seed(seed + 100)
+    x = torch.rand(S, patches, pixels, generator=g) * 2 - 1
+    if kind == "xe":
+        lab = torch.randint(0, C + 1, (S,), generator=g)
+        y = torch.nn.functional.one_hot(lab, C + 1).to(torch.float64)
+    else:
+        y = torch.randn(S, C, generator=g)
+    d = {"N": N, "patches": patches, "pixels": pixels, "r": r, "CB": CB, "C": C, "S": S, "seed": seed, "x": x, "y": y,
+         "loss_kind": np.array(kind), "train_names": np.array([n.name for n in tn.train_nodes])}
+    for i, t in enumerate(_snap_train(tn)):
+        d[f"node{i}"] = t
+    loss_fn = make_loss(kind)
+    y_pred = tn.forward(x, to_tensor=True)
+    loss, gr, H = loss_fn.forward(y_pred, y)
+    d["y_pred"], d["loss"], d["g"], d["H"] = y_pred, loss, gr, H
+    v_gen = torch.Generator().manual_seed(seed + 7)
+    for k, node in enumerate(tn.train_nodes):
+        A, b = tn.get_A_b(node, gr, H)
+        d[f"A{k}"], d[f"b{k}"] = A, b
+        v = torch.randn(node.tensor.shape, generator=v_gen)
+        pj = tn.get_J(node, gr)
+        coeff = torch.einsum(f"{pj['einsum']},{pj['node_ein']},{pj['dd_loss_ein']}->{pj['coeff_ein']}", pj['J'].tensor, v, H)
+        Av = torch.einsum(f"{pj['einsum']},{pj['d_loss_ein']}->{pj['node_ein']}", pj['J'].tensor, coeff)
+        d[f"v{k}"], d[f"Av{k}"] = v, Av
+    # one ridge_cholesky sweep and one Lanczos sweep, each from the same seeded start
+    for which in ("chol", "lanczos"):
+        layer2 = _conv_layer(N, r, patches, pixels, C, CB, seed)
+        tn2 = layer2.tensor_network
+        snaps, losses = [], []
+        if which == "chol":
+            ok = tn2.accumulating_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=1, method="ridge_cholesky", eps=1.0,
+                                        eps_decay=0.5, loss_callback=lambda NS, n, l: losses.append(l),
+                                        block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+        else:
+            torch.manual_seed(seed + 5)
+            for u, n in enumerate(tn2.train_nodes):
+                d[f"lanczos_x0_{u}"] = torch.randn_like(n.tensor)
+            torch.manual_seed(seed + 5)
+            ok = tn2.lanczos_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=1, max_iter=5, tol=1e-6,
+                                   loss_callback=lambda l: losses.append(l),
+                                   block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+        d[f"{which}_ok"] = int(ok)
+        d[f"{which}_losses"] = np.array(losses)
+        d[f"{which}_num_updates"] = len(snaps)
+        for u, snap in enumerate(snaps):
+            for i, t in enumerate(snap):
+                d[f"{which}_u{u}_node{i}"] = t
+    d["lanczos_torch_seed"] = seed + 5
+    npz(f"conv_tt_{tag}", **d)
+
+
+def gen_extra():
+    gen_conv("cbm1", 3, 10, 5, 4, -1, 3, 64, 41)
+    gen_conv("cb2", 3, 10, 5, 4, 2, 3, 64, 42)
+    gen_conv("cb2_sq_c1", 3, 6, 4, 3, 2, 1, 48, 43, kind="square")
+
+
+if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_EXTRA", "1") == "1":
+    gen_extra()

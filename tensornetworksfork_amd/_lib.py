@@ -20,9 +20,10 @@ _dbl = ctypes.c_double
 # name -> (restype, argtypes); must list every symbol include/ttk.h declares
 SIGNATURES = {
     "ttk_version": (_int, []),
-    "ttk_env_step_left_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
-    "ttk_env_step_right_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
-    "ttk_predict_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
+    "ttk_env_step_left_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
+    "ttk_env_step_right_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_predict_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
+    "ttk_kr_rows_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_loss_f64": (_int, [_int, _dbl, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _c_dp]),
     "ttk_batch_mean_f64": (_int, [_c_dp, _i64, _int, _i64, _c_dp, _c_dp]),
     "ttk_hess_left_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
@@ -33,7 +34,7 @@ SIGNATURES = {
     "ttk_gram_timing": (_int, [_int]),
     "ttk_gram_timing_read": (_int, [_c_dp, _int]),
     "ttk_rhs_ws_bytes": (_i64, [_i64, _int, _int, _int, _int]),
-    "ttk_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_jvp_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_solve_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _dbl, _c_dp, _i64, _c_dp]),
     "ttk_chol_ws_bytes": (_i64, [_int]),

@@ -33,7 +33,7 @@ static inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m 
 template <bool LEFT>
 __global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict__ E, const double* __restrict__ X,
                                                         const double* __restrict__ core, double* __restrict__ out,
-                                                        int64_t M, int C, int e, int p, int n, int KC) {
+                                                        int64_t M, int C, int e, int p, int n, int KC, int accumulate) {
   extern __shared__ double smem[];
   const int K = e * p;
   const int nb0 = blockIdx.y * 64;
@@ -121,14 +121,17 @@ __global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict_
       for (int t = 0; t < 4; ++t) {
         const int64_t row = row0 + kq + 4 * t;
         const int col = j * 16 + i;
-        if (row < M && col < nloc) out[row * n + nb0 + col] = acc[j][t];
+        if (row < M && col < nloc) {
+          double* o = out + row * n + nb0 + col;
+          *o = accumulate ? *o + acc[j][t] : acc[j][t];
+        }
       }
     }
   }
 }
 
 static int env_step_launch(bool left, const double* E, const double* X, const double* core, double* out, int64_t M,
-                           int C, int e, int p, int n, hipStream_t st) {
+                           int C, int e, int p, int n, int accumulate, hipStream_t st) {
   const int K = e * p;
   int KC = round_up(K, 4);
   const int kc_max = (48 * 1024) / (64 * 8);  // 96 rows of 64 doubles = 48 KiB
@@ -137,9 +140,9 @@ static int env_step_launch(bool left, const double* E, const double* X, const do
   if (lds > 150 * 1024) return TTK_EINVAL;
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)((n + 63) / 64));
   if (left)
-    hipLaunchKernelGGL(env_step_kernel<true>, grid, dim3(256), lds, st, E, X, core, out, M, C, e, p, n, KC);
+    hipLaunchKernelGGL(env_step_kernel<true>, grid, dim3(256), lds, st, E, X, core, out, M, C, e, p, n, KC, accumulate);
   else
-    hipLaunchKernelGGL(env_step_kernel<false>, grid, dim3(256), lds, st, E, X, core, out, M, C, e, p, n, KC);
+    hipLaunchKernelGGL(env_step_kernel<false>, grid, dim3(256), lds, st, E, X, core, out, M, C, e, p, n, KC, accumulate);
   return ttk_launch_status();
 }
 
@@ -147,7 +150,7 @@ static int env_step_launch(bool left, const double* E, const double* X, const do
 // y[s,c] = sum_r L[s,c,r] R[s,r]; 8 lanes per output row, shuffle reduction.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__ L, const double* __restrict__ R,
-                                                       double* __restrict__ y, int64_t M, int C, int r) {
+                                                       double* __restrict__ y, int64_t M, int C, int r, int accumulate) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
   double acc = 0.0;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__
   acc += __shfl_xor(acc, 4, 8);
   acc += __shfl_xor(acc, 2, 8);
   acc += __shfl_xor(acc, 1, 8);
-  if (row < M && sub == 0) y[row] = acc;
+  if (row < M && sub == 0) y[row] = accumulate ? y[row] + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -240,6 +243,22 @@ __global__ __launch_bounds__(1024) void batch_mean_kernel(const double* __restri
     for (int k = 0; k < 16; ++k) t += wsum[k];
     out[0] = t / (double)nb;
   }
+}
+
+// J[s,c,(l,p,r)] (+)= L[s,c,l] X[s,p] R[s,r]: explicit Jacobian rows, only for local problems that are
+// not a single Khatri-Rao term (conv-featurised columns with a conv bond).
+__global__ __launch_bounds__(256) void kr_rows_kernel(const double* __restrict__ L, const double* __restrict__ X,
+                                                       const double* __restrict__ R, double* __restrict__ J, int64_t S,
+                                                       int C, int rl, int p, int rr, int accumulate) {
+  const int64_t D = (int64_t)rl * p * rr;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * C * D) return;
+  const int64_t sc = idx / D;
+  const int k = (int)(idx - sc * D);
+  const int r = k % rr, lp = k / rr, pp = lp % p, l = lp / p;
+  const int64_t s_ = sc / C;
+  const double v = L[sc * rl + l] * X[s_ * p + pp] * R[s_ * rr + r];
+  J[idx] = accumulate ? J[idx] + v : v;
 }
 
 // HL[s,d,l] = sum_c H[s,c,d] L[s,c,l]
@@ -508,10 +527,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
 
 // out[i] = sum_k partial[k*stride + i], fixed order
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restrict__ partial, int nslabs,
-                                                            int64_t stride, int64_t n, double* __restrict__ out) {
+                                                            int64_t stride, int64_t n, double* __restrict__ out,
+                                                            int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
-  double acc = 0.0;
+  double acc = accumulate ? out[idx] : 0.0;
   for (int k = 0; k < nslabs; ++k) acc += partial[(int64_t)k * stride + idx];
   out[idx] = acc;
 }
@@ -1213,25 +1233,25 @@ int ttk_gram_timing_read(double* ms_out, int max) {
 int ttk_version(void) { return 100; }
 
 int ttk_env_step_left_f64(const double* E, const double* X, const double* core, double* out, int64_t S, int C, int rl,
-                          int p, int rr, void* stream) {
+                          int p, int rr, int accumulate, void* stream) {
   if (!E || !X || !core || !out || S < 0 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   if (S == 0) return TTK_OK;
-  return env_step_launch(true, E, X, core, out, S * C, C, rl, p, rr, (hipStream_t)stream);
+  return env_step_launch(true, E, X, core, out, S * C, C, rl, p, rr, accumulate, (hipStream_t)stream);
 }
 
 int ttk_env_step_right_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
-                           int rr, void* stream) {
+                           int rr, int accumulate, void* stream) {
   if (!R || !X || !core || !out || S < 0 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   if (S == 0) return TTK_OK;
-  return env_step_launch(false, R, X, core, out, S, 1, rr, p, rl, (hipStream_t)stream);
+  return env_step_launch(false, R, X, core, out, S, 1, rr, p, rl, accumulate, (hipStream_t)stream);
 }
 
-int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int C, int r, void* stream) {
+int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int C, int r, int accumulate, void* stream) {
   if (!L || !R || !y || S < 0 || C < 1 || r < 1) return TTK_EINVAL;
   if (S == 0) return TTK_OK;
   const int64_t M = S * C;
   hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((M * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L, R, y,
-                     M, C, r);
+                     M, C, r, accumulate);
   return ttk_launch_status();
 }
 
@@ -1247,6 +1267,16 @@ int ttk_loss_f64(int kind, double w, const double* y_pred, const double* y, doub
 int ttk_batch_mean_f64(const double* v, int64_t S, int n_per_sample, int64_t batch, double* out, void* stream) {
   if (!v || !out || S < 1 || n_per_sample < 1 || batch < 1) return TTK_EINVAL;
   hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, S, n_per_sample, batch, out);
+  return ttk_launch_status();
+}
+
+int ttk_kr_rows_f64(const double* L, const double* X, const double* R, double* J, int64_t S, int C, int rl, int p, int rr,
+                    int accumulate, void* stream) {
+  if (!L || !X || !R || !J || S < 0 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  if (S == 0) return TTK_OK;
+  const int64_t n = S * C * (int64_t)rl * p * rr;
+  hipLaunchKernelGGL(kr_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L, X, R, J, S,
+                     C, rl, p, rr, accumulate);
   return ttk_launch_status();
 }
 
@@ -1295,7 +1325,7 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 1) {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((d.gsize + 255) / 256)), dim3(256), 0, st, partial,
-                       d.nslabs, d.gsize, d.gsize, G);
+                       d.nslabs, d.gsize, d.gsize, G, 0);
     rc = ttk_launch_status();
   }
   return rc;
@@ -1390,7 +1420,7 @@ int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {
 }
 
 int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C, int rl,
-                int p, int rr, void* ws, int64_t ws_bytes, void* stream) {
+                int p, int rr, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
   if (!L || !X || !R || !g || !b || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const RhsDims d = rhs_dims(S, C, rl, p, rr);
   if (d.CH < 4) return TTK_EINVAL;
@@ -1403,7 +1433,7 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)ws,
-                     d.nslabs, D, D, b);
+                     d.nslabs, D, D, b, accumulate);
   return ttk_launch_status();
 }
 
@@ -1411,7 +1441,7 @@ int ttk_jvp_f64(const double* L, const double* X, const double* R, const double*
                 double* hu, int64_t S, int C, int rl, int p, int rr, void* stream) {
   if (!L || !X || !R || !H || !v || !tmp || !hu || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  int rc = env_step_launch(true, L, X, v, tmp, S * C, C, rl, p, rr, st);
+  int rc = env_step_launch(true, L, X, v, tmp, S * C, C, rl, p, rr, 0, st);
   if (rc != TTK_OK) return rc;
   hipLaunchKernelGGL(jvp_finish_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, tmp, R, H, hu, S, C, rr);
   return ttk_launch_status();

@@ -30,39 +30,45 @@ def prep(t):
     return t.contiguous()
 
 
-def env_step_left(E, X, core):
-    """E (S,C,rl), X (S,p), core (rl,p,rr) -> (S,C,rr)."""
+def env_step_left(E, X, core, out=None):
+    """E (S,C,rl), X (S,p), core (rl,p,rr) -> (S,C,rr); with `out` given the result is added to it."""
     S, C, rl = E.shape
     p, rr = core.shape[1], core.shape[2]
-    out = torch.empty((S, C, rr), dtype=F64, device=E.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((S, C, rr), dtype=F64, device=E.device)
     if S == 0:
         return out
     rc = _lib.lib().ttk_env_step_left_f64(_chk(E, "E"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
-                                          out.data_ptr(), S, C, rl, p, rr, _stream(E))
+                                          _chk(out, "out", (S, C, rr)), S, C, rl, p, rr, int(acc), _stream(E))
     _lib.check(rc, "ttk_env_step_left_f64")
     return out
 
 
-def env_step_right(R, X, core):
-    """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl)."""
+def env_step_right(R, X, core, out=None):
+    """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl); with `out` given the result is added to it."""
     S, rr = R.shape
     rl, p = core.shape[0], core.shape[1]
-    out = torch.empty((S, rl), dtype=F64, device=R.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((S, rl), dtype=F64, device=R.device)
     if S == 0:
         return out
     rc = _lib.lib().ttk_env_step_right_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
-                                           out.data_ptr(), S, rl, p, rr, _stream(R))
+                                           _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
     _lib.check(rc, "ttk_env_step_right_f64")
     return out
 
 
-def predict(L, R):
-    """L (S,C,r), R (S,r) -> (S,C)."""
+def predict(L, R, out=None):
+    """L (S,C,r), R (S,r) -> (S,C); with `out` given the result is added to it."""
     S, C, r = L.shape
-    y = torch.empty((S, C), dtype=F64, device=L.device)
+    acc = out is not None
+    y = out if acc else torch.empty((S, C), dtype=F64, device=L.device)
     if S == 0:
         return y
-    rc = _lib.lib().ttk_predict_f64(_chk(L, "L"), _chk(R, "R", (S, r)), y.data_ptr(), S, C, r, _stream(L))
+    rc = _lib.lib().ttk_predict_f64(_chk(L, "L"), _chk(R, "R", (S, r)), _chk(y, "y", (S, C)), S, C, r, int(acc),
+                                    _stream(L))
     _lib.check(rc, "ttk_predict_f64")
     return y
 
@@ -94,6 +100,18 @@ def batch_mean(v, batch):
     rc = _lib.lib().ttk_batch_mean_f64(_chk(v, "v"), S, nps, int(batch), out.data_ptr(), _stream(v))
     _lib.check(rc, "ttk_batch_mean_f64")
     return out
+
+
+def kr_rows(L, X, R, out=None):
+    """Explicit Jacobian rows (S,C,rl*p*rr) of one Khatri-Rao term; added to `out` when given."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    acc = out is not None
+    J = out if acc else torch.empty((S, C, rl * p * rr), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_kr_rows_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
+                                    _chk(J, "J", (S, C, rl * p * rr)), S, C, rl, p, rr, int(acc), _stream(L))
+    _lib.check(rc, "ttk_kr_rows_f64")
+    return J
 
 
 def hess_left(H, L):
@@ -166,8 +184,8 @@ def gram_expand(ws, scale=None, ridge=0.0, out=None):
 _rhs_ws = {}
 
 
-def rhs(L, X, R, g):
-    """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]."""
+def rhs(L, X, R, g, out=None):
+    """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]; with `out` given the result is added to it."""
     S, C, rl = L.shape
     p, rr = X.shape[1], R.shape[1]
     nbytes = _lib.lib().ttk_rhs_ws_bytes(S, C, rl, p, rr)
@@ -179,9 +197,11 @@ def rhs(L, X, R, g):
         _rhs_ws.clear()
         ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
         _rhs_ws[key] = ws
-    b = torch.empty((rl, p, rr), dtype=F64, device=L.device)
+    acc = out is not None
+    b = out if acc else torch.empty((rl, p, rr), dtype=F64, device=L.device)
     rc = _lib.lib().ttk_rhs_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(g, "g", (S, C)),
-                                b.data_ptr(), S, C, rl, p, rr, ws.data_ptr(), int(nbytes), _stream(L))
+                                _chk(b, "b", (rl, p, rr)), S, C, rl, p, rr, int(acc), ws.data_ptr(), int(nbytes),
+                                _stream(L))
     _lib.check(rc, "ttk_rhs_f64")
     return b
 

@@ -1,0 +1,487 @@
+"""Chain engine: the arithmetic behind TensorNetwork for tensor-train shaped graphs.
+
+Two column shapes are recognised (one column = one site of the train):
+
+  plain      A_k (rl,[c],p,rr)  --p--  X_k (S,p)                       tensor/layers.py:194-221
+  conv       A_k (rl,[c],patches,rr) --patches-- X_k (S,patches,pixels) --pixels-- C_k ([a],pixels,[b])
+                                                                       tensor/layers.py:791-890
+
+A conv column is a plain column whose feature vector depends on the sample through the conv
+node: G_k[a,b][s,patch] = sum_x X_k[s,patch,x] C_k[a,x,b]; with a conv bond (a,b) the
+environments carry the composite bond (r,b) and every contraction of the plain train becomes a
+sum over (a,b) of the same Khatri-Rao kernels (accumulating launches).  A plain column is the
+special case a = b = 1 with G = X.
+
+Per-sample environments of a whole data set stay resident on the device (`_Data`) and are
+dropped only where a node of an earlier / later column changed.
+"""
+import torch
+
+from .. import ops
+
+F64 = torch.float64
+
+
+class _Column:
+    __slots__ = ("A", "Cn", "xin", "order", "nleft", "out_labels", "sizes", "rl", "p", "rr",
+                 "c_order", "c_sizes", "ca", "cb", "px")
+
+
+class _Data:
+    """One data set resident on the device with its cached features and environments."""
+
+    def __init__(self, raw, xs, N):
+        self.raw = raw
+        self.xs = xs
+        self.S = xs[0].shape[0]
+        self.S_total = self.S
+        self.sharded = False
+        self.L = [None] * N
+        self.R = [None] * N
+        self.G = [None] * N
+        self.seenA = [None] * N    # (tensor, version) of A_k / C_k when the caches were last valid
+        self.seenC = [None] * N
+
+    def matches(self, raw):
+        return len(raw) == len(self.raw) and all(a is b for a, b in zip(raw, self.raw))
+
+
+def _changed(seen, node):
+    if node is None:
+        return False
+    t = node.tensor
+    return seen is None or seen[0] is not t or seen[1] != t._version
+
+
+class LocalProblem:
+    """The normal equations of one train node for a bound data set.
+
+    Either a list of Khatri-Rao terms (L (S,C,rl), X (S,p), R (S,rr)) whose sum is the
+    Jacobian, or explicit Jacobian rows J (S,C,D).  `core` is the node's tensor in canonical
+    (flattened) order; `back` maps a canonical vector to the node's own layout."""
+
+    def __init__(self, S, C, shape, core, back, terms=None, J=None):
+        self.S, self.C = S, C
+        self.shape = tuple(shape)       # canonical shape, prod = D
+        self.D = 1
+        for n in self.shape:
+            self.D *= n
+        self.core = core
+        self.back = back
+        self.terms = terms
+        self.J = J
+
+    # -- first order
+    def rhs(self, g):
+        """b = J^T g, canonical shape."""
+        if self.J is not None:
+            return (self.J.reshape(self.S * self.C, self.D).T @ g.reshape(self.S * self.C)).reshape(self.shape)
+        out = None
+        for (L, X, R) in self.terms:
+            out = ops.rhs(L, X, R, g) if out is None else ops.rhs(L, X, R, g, out=out)
+        return out
+
+    def jv(self, v):
+        """u[s,c] = J v."""
+        if self.J is not None:
+            return (self.J.reshape(self.S * self.C, self.D) @ v.reshape(self.D)).reshape(self.S, self.C)
+        v = v.reshape(self.shape)
+        u = None
+        tmp = {}
+        for (L, X, R) in self.terms:     # terms that share R share one environment-step buffer
+            key = id(R)
+            if key in tmp:
+                ops.env_step_left(L, X, v, out=tmp[key][0])
+            else:
+                tmp[key] = (ops.env_step_left(L, X, v), R)
+        for t, R in tmp.values():
+            u = ops.predict(t, R) if u is None else ops.predict(t, R, out=u)
+        return u
+
+    def matvec_fn(self, H):
+        """v -> (J^T H J) v, canonical shape, never forming the Gram matrix."""
+        if self.terms is not None and len(self.terms) == 1:
+            L, X, R = self.terms[0]
+            return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
+
+        def mv(v):
+            u = self.jv(v)
+            hu = ops.hess_left(H, u.unsqueeze(-1)).squeeze(-1)
+            return self.rhs(hu)
+        return mv
+
+    def slice(self, lo, hi):
+        """The same problem restricted to samples [lo, hi) (first-axis views, no copies)."""
+        if self.J is not None:
+            return LocalProblem(hi - lo, self.C, self.shape, self.core, self.back, J=self.J[lo:hi])
+        terms = [(L[lo:hi], X[lo:hi], R[lo:hi]) for (L, X, R) in self.terms]
+        return LocalProblem(hi - lo, self.C, self.shape, self.core, self.back, terms=terms)
+
+    # -- Gram
+    def single_term(self):
+        return self.terms is not None and len(self.terms) == 1
+
+    def rows(self, lo, hi):
+        """Explicit Jacobian rows of samples [lo, hi): (n, C, D)."""
+        if self.J is not None:
+            return self.J[lo:hi]
+        out = None
+        for (L, X, R) in self.terms:
+            a = (L[lo:hi].contiguous(), X[lo:hi].contiguous(), R[lo:hi].contiguous())
+            out = ops.kr_rows(*a) if out is None else ops.kr_rows(*a, out=out)
+        return out
+
+    def dense_gram(self, H, chunk_bytes=1 << 30):
+        """A (D,D) = sum_s J^T H J from explicit rows in sample chunks; the two large products
+        are plain library GEMMs (rocBLAS through torch.matmul)."""
+        D, C = self.D, self.C
+        A = torch.zeros((D, D), dtype=F64, device=H.device)
+        step = max(1, int(chunk_bytes // (8 * C * D)))
+        for lo in range(0, self.S, step):
+            hi = min(self.S, lo + step)
+            J = self.rows(lo, hi)
+            HJ = ops.hess_left(H[lo:hi].contiguous(), J.contiguous())     # (n,C,D): sum_c H[s,c,d] J[s,c,:]
+            A.addmm_(J.reshape(-1, D).T, HJ.reshape(-1, D))
+        return A
+
+
+class ChainEngine:
+    def __init__(self, net):
+        self.net = net
+        self.error = None
+        self.cols = None
+        try:
+            self.cols = self._plan()
+        except ValueError as e:
+            self.error = str(e)
+        self.datasets = []
+        self._gram_ws = {}
+        self._abuf = {}
+
+    # ------------------------------------------------------------------ topology
+    def _plan(self):
+        net = self.net
+        N = len(net.main_nodes)
+        outs = [lab for lab in (net.output_labels or ()) if lab != net.sample_dim]
+        if len(net.input_nodes) != N:
+            raise ValueError("expected one input node per core")
+        cols = []
+        used = set()
+        for i, node in enumerate(net.main_nodes):
+            col = _Column()
+            col.A = node
+            phys = [(lab, o) for lab, o in node.connections.items() if not node.is_horizontal_bond(lab)]
+            if len(phys) != 1 or phys[0][1] not in net.input_nodes:
+                raise ValueError(f"{node.name}: expected exactly one input edge")
+            plab, xin = phys[0]
+            col.xin = net.input_nodes.index(xin)
+            used.update([node, xin])
+            left = [lab for lab in node.left_labels if lab in node.dim_labels]
+            right = [lab for lab in node.right_labels if lab in node.dim_labels]
+            col.out_labels = [lab for lab in node.dim_labels if lab in outs]
+            if col.out_labels and i != 0:
+                raise ValueError("output labels are supported on the first core only")
+            if i > 0 and (len(left) != 1 or node.connections.get(left[0]) is not net.main_nodes[i - 1]):
+                raise ValueError(f"{node.name}: left bond does not reach the previous core")
+            if i < N - 1 and (len(right) != 1 or node.connections.get(right[0]) is not net.main_nodes[i + 1]):
+                raise ValueError(f"{node.name}: right bond does not reach the next core")
+            col.order = left + col.out_labels + [plab] + right
+            col.nleft = len(left) + len(col.out_labels)
+            if sorted(col.order) != sorted(node.dim_labels):
+                raise ValueError(f"{node.name}: unexpected labels {node.dim_labels}")
+            # input node: (s, p) plain, or (s, patches, pixels) with a conv node on `pixels`
+            xl = list(xin.dim_labels)
+            others = [(lab, o) for lab, o in xin.connections.items() if o is not node]
+            if xl == [net.sample_dim, plab] and not others:
+                col.Cn = None
+                col.c_order = None
+            elif len(xl) == 3 and xl[0] == net.sample_dim and xl[1] == plab and len(others) == 1 and others[0][0] == xl[2]:
+                cn = others[0][1]
+                col.Cn = cn
+                used.add(cn)
+                cl = [lab for lab in cn.left_labels if lab in cn.dim_labels]
+                cr = [lab for lab in cn.right_labels if lab in cn.dim_labels]
+                col.c_order = cl + [xl[2]] + cr
+                if sorted(col.c_order) != sorted(cn.dim_labels) or len(cl) > 1 or len(cr) > 1:
+                    raise ValueError(f"{cn.name}: unexpected labels {cn.dim_labels}")
+                if cl and (i == 0 or cn.connections.get(cl[0]) is not cols[i - 1].Cn):
+                    raise ValueError(f"{cn.name}: left conv bond does not reach the previous conv node")
+            else:
+                raise ValueError(f"{xin.name}: unsupported input column {xl}")
+            cols.append(col)
+        if len(used) != len(net.nodes):
+            raise ValueError("nodes outside the recognised columns")
+        for t in net.train_nodes:
+            if t not in used or t in net.input_nodes:
+                raise ValueError("train nodes outside the recognised columns")
+        # an output label that no node carries was a size-1 axis squeezed away at construction
+        return cols
+
+    def require(self):
+        if self.cols is None:
+            raise NotImplementedError("this build runs tensor-train shaped networks (plain or conv-featurised "
+                                      f"columns) on the HIP path; topology not recognised: {self.error}")
+        return self.cols
+
+    # ------------------------------------------------------------------ canonical views
+    def canonA(self, k):
+        col = self.cols[k]
+        node = col.A
+        perm = [node.dim_labels.index(lab) for lab in col.order]
+        t = node.tensor.permute(perm) if perm != list(range(len(perm))) else node.tensor
+        sizes = list(t.shape)
+        rl = 1
+        for n in sizes[:col.nleft]:
+            rl *= n
+        rr = 1
+        for n in sizes[col.nleft + 1:]:
+            rr *= n
+        col.sizes, col.rl, col.p, col.rr = sizes, rl, sizes[col.nleft], rr
+        return ops.prep(t.reshape(rl, col.p, rr))
+
+    def backA(self, k, t):
+        col = self.cols[k]
+        node = col.A
+        perm = [node.dim_labels.index(lab) for lab in col.order]
+        t = t.reshape(col.sizes)
+        inv = [perm.index(a) for a in range(len(perm))]
+        if inv != list(range(len(inv))):
+            t = t.permute(inv)
+        return t.to(node.tensor.dtype)
+
+    def permA(self, k):
+        col = self.cols[k]
+        return [col.A.dim_labels.index(lab) for lab in col.order]
+
+    def canonC(self, k):
+        """(ca, pixels, cb) view of the conv node of column k."""
+        col = self.cols[k]
+        cn = col.Cn
+        perm = [cn.dim_labels.index(lab) for lab in col.c_order]
+        t = cn.tensor.permute(perm) if perm != list(range(len(perm))) else cn.tensor
+        sizes = list(t.shape)
+        nl = len([lab for lab in cn.left_labels if lab in cn.dim_labels])
+        ca = sizes[0] if nl else 1
+        px = sizes[nl]
+        cb = sizes[nl + 1] if len(sizes) > nl + 1 else 1
+        col.c_sizes, col.ca, col.px, col.cb = sizes, ca, px, cb
+        return ops.prep(t.reshape(ca, px, cb))
+
+    def backC(self, k, t):
+        col = self.cols[k]
+        cn = col.Cn
+        perm = [cn.dim_labels.index(lab) for lab in col.c_order]
+        t = t.reshape(col.c_sizes)
+        inv = [perm.index(a) for a in range(len(perm))]
+        if inv != list(range(len(inv))):
+            t = t.permute(inv)
+        return t.to(cn.tensor.dtype)
+
+    def permC(self, k):
+        col = self.cols[k]
+        return [col.Cn.dim_labels.index(lab) for lab in col.c_order]
+
+    def layout(self, node):
+        """(canonical multi-axis sizes, permutation node axes -> canonical axes) of a train node."""
+        k, kind = self.column_of(node)
+        if kind == "A":
+            self.canonA(k)
+            return self.cols[k].sizes, self.permA(k)
+        self.canonC(k)
+        return self.cols[k].c_sizes, self.permC(k)
+
+    def out_dim(self):
+        col = self.cols[0]
+        C = 1
+        for lab in col.out_labels:
+            C *= col.A.dim_size(lab)
+        return C
+
+    def column_of(self, node):
+        for k, col in enumerate(self.cols):
+            if node is col.A:
+                return k, "A"
+            if node is col.Cn:
+                return k, "C"
+        raise ValueError("node is not a trainable node of this network")
+
+    # ------------------------------------------------------------------ data sets
+    def site_list(self, x):
+        cols = self.require()
+        per_input = list(x) if isinstance(x, (tuple, list)) else [x] * len(self.net.input_nodes)
+        return [per_input[col.xin] for col in cols]
+
+    def data_for(self, x, shard=None):
+        raw = self.site_list(x)
+        for d in self.datasets:
+            if d.matches(raw) and d.sharded == (shard is not None):
+                self.datasets.remove(d)
+                self.datasets.append(d)
+                return d
+        device = self.net.main_nodes[0].tensor.device
+        done, xs = {}, []
+        for col, t in zip(self.cols, raw):
+            if id(t) not in done:
+                tt = t if shard is None else shard.rows(t)
+                tt = tt.to(device) if tt.device != device else tt
+                want = 2 if col.Cn is None else 3
+                if tt.ndim != want:
+                    raise ValueError(f"expected a {want}-d input (samples, features{', pixels' if want == 3 else ''}), "
+                                     f"got shape {tuple(tt.shape)}")
+                done[id(t)] = ops.prep(tt)
+            xs.append(done[id(t)])
+        d = _Data(raw, xs, len(raw))
+        d.sharded = shard is not None
+        d.S_total = raw[0].shape[0]
+        self.datasets.append(d)
+        if len(self.datasets) > 3:
+            self.datasets.pop(0)
+        return d
+
+    def sync(self, d):
+        """Drop cached features / environments that depend on a node that changed."""
+        N = len(self.cols)
+        first, last = None, None
+        for j, col in enumerate(self.cols):
+            ca, cc = _changed(d.seenA[j], col.A), _changed(d.seenC[j], col.Cn)
+            if cc:
+                d.G[j] = None
+                d.seenC[j] = (col.Cn.tensor, col.Cn.tensor._version)
+            if ca:
+                d.seenA[j] = (col.A.tensor, col.A.tensor._version)
+            if ca or cc:
+                first = j if first is None else first
+                last = j
+        if first is not None:
+            for k in range(first + 1, N):
+                d.L[k] = None
+            for k in range(0, last):
+                d.R[k] = None
+
+    # ------------------------------------------------------------------ features and environments
+    def feats(self, d, k):
+        """G_k: (ca, cb, S, p) feature vectors per conv-bond pair (a plain column: X itself)."""
+        if d.G[k] is None:
+            col = self.cols[k]
+            X = d.xs[k]
+            if col.Cn is None:
+                d.G[k] = X.reshape(1, 1, *X.shape)
+            else:
+                Cc = self.canonC(k)                                   # (ca, px, cb)
+                S, p, px = X.shape
+                flat = X.reshape(S * p, px) @ Cc.permute(1, 0, 2).reshape(px, col.ca * col.cb)   # library GEMM
+                d.G[k] = flat.reshape(S, p, col.ca, col.cb).permute(2, 3, 0, 1).contiguous()
+        return d.G[k]
+
+    def left(self, d, k):
+        """Environment entering column k from the left: (ca_k, S, C, rl_k)."""
+        if d.L[k] is None:
+            if k == 0:
+                C = self.out_dim()
+                eye = torch.eye(C, dtype=F64, device=d.xs[0].device)
+                d.L[0] = eye.unsqueeze(0).expand(d.S, C, C).contiguous().unsqueeze(0)
+            else:
+                d.L[k] = self.left_step(d, k - 1, self.canonA(k - 1))
+        return d.L[k]
+
+    def left_step(self, d, k, core):
+        """Column k applied to the left environment with `core` in place of A_k: (cb_k, S, C, rr_k)."""
+        Lk, G = self.left(d, k), self.feats(d, k)
+        ca, cb = G.shape[0], G.shape[1]
+        outs = []
+        for b in range(cb):
+            o = ops.env_step_left(Lk[0], G[0, b], core)
+            for a in range(1, ca):
+                ops.env_step_left(Lk[a], G[a, b], core, out=o)
+            outs.append(o)
+        return torch.stack(outs) if cb > 1 else outs[0].unsqueeze(0)
+
+    def right(self, d, k):
+        """Environment entering column k from the right: (cb_k, S, rr_k)."""
+        N = len(self.cols)
+        if d.R[k] is None:
+            if k == N - 1:
+                d.R[k] = torch.ones((1, d.S, 1), dtype=F64, device=d.xs[0].device)
+            else:
+                Rn, G, core = self.right(d, k + 1), self.feats(d, k + 1), self.canonA(k + 1)
+                ca, cb = G.shape[0], G.shape[1]
+                outs = []
+                for a in range(ca):
+                    o = ops.env_step_right(Rn[0], G[a, 0], core)
+                    for b in range(1, cb):
+                        ops.env_step_right(Rn[b], G[a, b], core, out=o)
+                    outs.append(o)
+                d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
+        return d.R[k]
+
+    def predict(self, d, k=None):
+        """(S, C) prediction, cut at column k (default: the cheapest cut)."""
+        self.sync(d)
+        N = len(self.cols)
+        if k is None:
+            vl = 0
+            while vl + 1 < N and d.L[vl + 1] is not None:
+                vl += 1
+            vr = N - 1
+            while vr - 1 >= 0 and d.R[vr - 1] is not None:
+                vr -= 1
+            k = min(range(N), key=lambda j: max(0, j - vl) + max(0, vr - j))
+        Lk1 = self.left_step(d, k, self.canonA(k))
+        R = self.right(d, k)
+        y = ops.predict(Lk1[0], R[0])
+        for b in range(1, R.shape[0]):
+            ops.predict(Lk1[b], R[b], out=y)
+        return y
+
+    # ------------------------------------------------------------------ local problems
+    def local(self, d, node):
+        self.sync(d)
+        k, kind = self.column_of(node)
+        L, R, G = self.left(d, k), self.right(d, k), self.feats(d, k)
+        S, C = d.S, L.shape[2]
+        core = self.canonA(k)
+        col = self.cols[k]
+        if kind == "A":
+            terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
+            return LocalProblem(S, C, (col.rl, col.p, col.rr), core, lambda t, k=k: self.backA(k, t), terms=terms)
+        # conv node: J[s,c,a,x,b] = sum_patch M_ab[s,c,patch] X[s,patch,x],
+        # M_ab = L_a . (A . R_b); all three products are plain (batched) library GEMMs
+        Cc = self.canonC(k)
+        X = d.xs[k]
+        ca, cb, px = col.ca, col.cb, col.px
+        J = torch.empty((S, C, ca, px, cb), dtype=F64, device=X.device)
+        A2 = core.reshape(col.rl * col.p, col.rr)
+        for b in range(cb):
+            U = (R[b] @ A2.T).reshape(S, col.rl, col.p)
+            for a in range(ca):
+                M = torch.bmm(L[a], U)                      # (S, C, p)
+                J[:, :, a, :, b] = torch.bmm(M, X)          # (S, C, px)
+        return LocalProblem(S, C, (ca, px, cb), Cc, lambda t, k=k: self.backC(k, t), J=J.reshape(S, C, ca * px * cb))
+
+    def to_canon(self, node, v):
+        k, kind = self.column_of(node)
+        col = self.cols[k]
+        if kind == "A":
+            self.canonA(k)
+            return ops.prep(v.permute(self.permA(k)).reshape(col.rl, col.p, col.rr))
+        self.canonC(k)
+        return ops.prep(v.permute(self.permC(k)).reshape(col.ca, col.px, col.cb))
+
+    # ------------------------------------------------------------------ Gram + solve
+    def gram_ws(self, lp, H, sym):
+        L, X, R = lp.terms[0]
+        key = (lp.S, lp.C, L.shape[2], X.shape[1], R.shape[1], int(sym))
+        ws = self._gram_ws.get(key)
+        if ws is None:
+            self._gram_ws.clear()
+        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
+        self._gram_ws[key] = ws
+        return ws
+
+    def dense_buffer(self, D, device):
+        buf = self._abuf.get(D)
+        if buf is None:
+            self._abuf.clear()
+            buf = torch.empty((D, D), dtype=F64, device=device)
+            self._abuf[D] = buf
+        return buf

@@ -180,3 +180,62 @@ class TensorTrainLayer(TensorNetworkLayer):
                 n.squeeze(self.main_node_layer.labels)
         self.set_tensor_network(TensorNetwork(self.input_node_layer.nodes, self.main_node_layer.nodes,
                                               output_labels=self.main_node_layer.labels))
+
+
+class TensorConvolutionTrainLayer(TensorNetworkLayer):
+    def __init__(self, num_carriages, bond_dim, num_patches, patch_pixels, output_shape, ring=False,
+                 convolution_bond=-1, dtype=None, constrict_bond=True, perturb=False):
+        """Tensor train over patches whose per-patch feature is a learned pixel filter
+        (tensor/layers.py:791-890).  Column i: X_i (s, patches, patch_pixels) -- C_i (patch_pixels) or
+        (CB_i, patch_pixels, CB_{i+1}) on 'patch_pixels', X_i -- A_i (r_i, c_i|c, patches, r_{i+1}) on
+        'patches'; A's chained on r, C's on CB.  Random tensors are drawn column by column in the
+        order X_i, C_i, A_i from the global generator; size-1 legs are squeezed away.
+        main_nodes = A's, train_nodes = [C1, A1, C2, A2, ...]."""
+        if ring:
+            raise NotImplementedError("Ring structure is not implemented for TensorConvolutionTrainLayer.")
+        N, CB = num_carriages, convolution_bond
+        self.num_carriages, self.bond_dim = N, bond_dim
+        self.num_patches, self.patch_pixels = num_patches, patch_pixels
+        self.output_shape = output_shape if isinstance(output_shape, tuple) else (output_shape,)
+        self.ring, self.convolution_bond = ring, CB
+        n_out = len(self.output_shape)
+        if perturb:
+            last = _perturb_block(bond_dim, num_patches, 1, dtype)
+            first = torch.randn((1, num_patches, bond_dim), dtype=dtype).unsqueeze(1)
+            lefts, specs = [first], [first, last]
+            for i in range(N - 2):
+                rl, rr = lefts[-1].shape[-1], last.shape[0]
+                if i == N - 3:
+                    specs = lefts + [_perturb_block(rl, num_patches, rr, dtype), last]
+                lefts.append(_perturb_block(rl, num_patches, bond_dim, dtype))
+        else:
+            specs = [(bond_dim if i > 1 else 1, self.output_shape[i - 1] if i <= n_out else 1, num_patches,
+                      bond_dim if i < N else 1) for i in range(1, N + 1)]
+        labels = ('s',) + tuple(f'c{i}' for i in range(1, min(N, n_out) + 1))
+        xs, convs, trains = [], [], []
+        for i in range(1, N + 1):
+            xs.append(TensorNode((1, num_patches, patch_pixels), ['s', 'patches', 'patch_pixels'], name=f"X{i}"))
+            if CB > 0:
+                convs.append(TensorNode((CB if i > 1 else 1, patch_pixels, CB if i < N else 1),
+                                        [f'CB{i}', 'patch_pixels', f'CB{i + 1}'], l=f'CB{i}', r=f'CB{i + 1}',
+                                        name=f"C{i}"))
+            else:
+                convs.append(TensorNode((patch_pixels,), ['patch_pixels'], name=f"C{i}"))
+            trains.append(TensorNode(specs[i - 1], [f'r{i}', f'c{i}' if i <= n_out else 'c', 'patches', f'r{i + 1}'],
+                                     l=f'r{i}', r=f'r{i + 1}', name=f"A{i}"))
+        order = []
+        for xn, cn, an in zip(xs, convs, trains):
+            xn.connect(an, 'patches')
+            cn.connect(xn, 'patch_pixels')
+            order += [cn, an]
+        for i in range(1, N):
+            trains[i - 1].connect(trains[i], f'r{i + 1}')
+            if CB > 0:
+                convs[i - 1].connect(convs[i], f'CB{i + 1}')
+        for n in trains + convs:
+            n.squeeze()
+        self.x_nodes, self.conv_blocks, self.train_blocks = xs, convs, trains
+        super().__init__(TensorNetwork(xs, trains, order, output_labels=labels))
+        self.nodes = order
+        self.input_nodes, self.main_nodes = xs, trains
+        self.train_nodes = trains + convs

@@ -2,12 +2,12 @@
 
 The reference contracts a labelled graph with generated torch.einsum calls and
 rebuilds every environment for every mini-batch.  Here the graph is inspected
-once: a plain tensor-train chain (one core and one input per site) is mapped to
-canonical (rl, p, rr) cores, the per-sample left/right environments of the
-whole data set stay resident in HBM and are refreshed only where a core
-changed, and all arithmetic runs in the HIP kernels of libttk.so.  Sums over
-mini-batches in the reference are sums over samples, so one pass over the full
-data gives the same Gram matrix, right-hand side and (batch-mean) loss.
+once (engine.ChainEngine): a tensor-train chain with plain or conv-featurised
+columns is mapped to canonical (rl, p, rr) cores, the per-sample left/right
+environments of the whole data set stay resident in HBM and are refreshed only
+where a node changed, and the arithmetic runs in the HIP kernels of libttk.so.
+Sums over mini-batches in the reference are sums over samples, so one pass over
+the full data gives the same Gram matrix, right-hand side and (batch-mean) loss.
 """
 import time
 from collections import deque
@@ -15,30 +15,12 @@ from collections import deque
 import torch
 
 from .. import ops
+from .engine import ChainEngine
 from .node import TensorNode
+from .solvers import (_cholesky_solve, _host_solver, _scipy_kind, cg_solve, lanczos_solve,  # noqa: F401
+                      minres_solve)
 
 _LEGACY_KWARGS = ("eps_r", "delta", "D_reg_fn")  # accepted and ignored: stale call sites pass them
-
-
-class _Site:
-    __slots__ = ("node", "xin", "order", "nleft", "sizes", "rl", "p", "rr", "out_labels")
-
-
-class _Data:
-    """One data set resident on the device with its cached environments."""
-
-    def __init__(self, raw, xs, N):
-        self.raw = raw
-        self.xs = xs
-        self.S = xs[0].shape[0]
-        self.L = [None] * N
-        self.R = [None] * N
-        self.seen = [None] * N     # (tensor object, version) of each core when envs were last valid
-        self.sharded = False
-        self.S_total = self.S
-
-    def matches(self, raw):
-        return len(raw) == len(self.raw) and all(a is b for a, b in zip(raw, self.raw))
 
 
 class TensorNetwork:
@@ -51,13 +33,9 @@ class TensorNetwork:
         self.output_labels = output_labels
         self.sample_dim = sample_dim
         self.nodes, self.node_indices = self._discover_nodes()
-        self._datasets = []
         self._current = None
-        self._gram_ws = {}
-        self._abuf = {}
-        self._chain_error = None
         self._shard = None
-        self._sites = self._plan_chain()
+        self._engine = ChainEngine(self)
 
     def distribute(self, shard="auto"):
         """Shard the training samples of the sweep methods over the ranks of a
@@ -66,7 +44,7 @@ class TensorNetwork:
         default process group when one is initialised."""
         from ..parallel import default_shard
         self._shard = default_shard() if shard == "auto" else shard
-        self._datasets = []
+        self._engine.datasets = []
         return self
 
     # ------------------------------------------------------------------ graph
@@ -83,53 +61,8 @@ class TensorNetwork:
                     queue.append(other)
         return sorted(index, key=lambda n: n.name), index
 
-    def _plan_chain(self):
-        """Recognise a plain TT chain: site i = main node i + exactly one input
-        node (S, p_i); output labels only on the first core."""
-        N = len(self.main_nodes)
-        try:
-            if len(self.input_nodes) != N or len(self.nodes) != 2 * N:
-                raise ValueError("expected one input node per core and no other nodes")
-            if any(t not in self.main_nodes for t in self.train_nodes):
-                raise ValueError("train nodes outside the chain")
-            outs = [lab for lab in (self.output_labels or ()) if lab != self.sample_dim]
-            sites = []
-            for i, node in enumerate(self.main_nodes):
-                st = _Site()
-                st.node = node
-                phys = [(lab, o) for lab, o in node.connections.items() if not node.is_horizontal_bond(lab)]
-                if len(phys) != 1 or phys[0][1] not in self.input_nodes:
-                    raise ValueError(f"{node.name}: expected exactly one input edge")
-                plab, xin = phys[0]
-                st.xin = self.input_nodes.index(xin)
-                if list(xin.dim_labels) != [self.sample_dim, plab]:
-                    raise ValueError(f"{xin.name}: expected labels [sample, {plab}]")
-                left = [lab for lab in node.left_labels if lab in node.dim_labels]
-                right = [lab for lab in node.right_labels if lab in node.dim_labels]
-                st.out_labels = [lab for lab in node.dim_labels if lab in outs]
-                if st.out_labels and i != 0:
-                    raise ValueError("output labels are supported on the first core only")
-                if i > 0 and (len(left) != 1 or node.connections.get(left[0]) is not self.main_nodes[i - 1]):
-                    raise ValueError(f"{node.name}: left bond does not reach the previous core")
-                if i < N - 1 and (len(right) != 1 or node.connections.get(right[0]) is not self.main_nodes[i + 1]):
-                    raise ValueError(f"{node.name}: right bond does not reach the next core")
-                st.order = left + st.out_labels + [plab] + right
-                st.nleft = len(left) + len(st.out_labels)
-                if sorted(st.order) != sorted(node.dim_labels):
-                    raise ValueError(f"{node.name}: unexpected labels {node.dim_labels}")
-                sites.append(st)
-            if outs and sorted(outs) != sorted(sites[0].out_labels):
-                raise ValueError("output labels missing from the first core")
-            return sites
-        except ValueError as e:
-            self._chain_error = str(e)
-            return None
-
     def _require_chain(self):
-        if self._sites is None:
-            raise NotImplementedError("this build runs plain tensor-train chains on the HIP path; "
-                                      f"topology not recognised: {self._chain_error}")
-        return self._sites
+        return self._engine.require()
 
     def get_column_nodes(self, node):
         i = self.node_indices[node]
@@ -146,138 +79,18 @@ class TensorNetwork:
             n.to(device=device, dtype=dtype)
         return self
 
-    # ------------------------------------------------------------------ canonical cores
-    def _canon(self, i):
-        """(rl, p, rr) float64 contiguous view/copy of core i, in the site's label order."""
-        st = self._sites[i]
-        node = st.node
-        perm = [node.dim_labels.index(lab) for lab in st.order]
-        t = node.tensor.permute(perm) if perm != list(range(len(perm))) else node.tensor
-        sizes = list(t.shape)
-        nl = st.nleft
-        rl = 1
-        for s_ in sizes[:nl]:
-            rl *= s_
-        p = sizes[nl]
-        rr = 1
-        for s_ in sizes[nl + 1:]:
-            rr *= s_
-        st.sizes, st.rl, st.p, st.rr = sizes, rl, p, rr
-        return ops.prep(t.reshape(rl, p, rr))
-
-    def _from_canon(self, i, t):
-        """Canonical (rl,p,rr) tensor -> the node's own axis order and dtype."""
-        st = self._sites[i]
-        node = st.node
-        perm = [node.dim_labels.index(lab) for lab in st.order]
-        t = t.reshape(st.sizes)
-        inv = [perm.index(a) for a in range(len(perm))]
-        if inv != list(range(len(inv))):
-            t = t.permute(inv)
-        return t.to(node.tensor.dtype)
-
-    def _out_dim(self):
-        st = self._sites[0]
-        C = 1
-        for lab in st.out_labels:
-            C *= st.node.dim_size(lab)
-        return C
-
     # ------------------------------------------------------------------ data sets
-    def _site_list(self, x):
-        N = len(self.main_nodes)
-        if isinstance(x, (tuple, list)):
-            per_input = list(x)
-        else:
-            per_input = [x] * len(self.input_nodes)
-        sites = self._require_chain()
-        return [per_input[st.xin] for st in sites]
-
     def _data_for(self, x, shard=None):
-        raw = self._site_list(x)
-        for d in self._datasets:
-            if d.matches(raw) and d.sharded == (shard is not None):
-                self._datasets.remove(d)
-                self._datasets.append(d)
-                return d
-        device = self.main_nodes[0].tensor.device
-        done = {}
-        xs = []
-        for t in raw:
-            if id(t) not in done:
-                tt = t if shard is None else shard.rows(t)
-                tt = tt.to(device) if tt.device != device else tt
-                if tt.ndim != 2:
-                    raise ValueError(f"expected (samples, features) inputs, got shape {tuple(tt.shape)}")
-                done[id(t)] = ops.prep(tt)
-            xs.append(done[id(t)])
-        d = _Data(raw, xs, len(raw))
-        d.sharded = shard is not None
-        d.S_total = raw[0].shape[0]
-        self._datasets.append(d)
-        if len(self._datasets) > 3:
-            self._datasets.pop(0)
-        return d
-
-    def _sync(self, d):
-        """Drop cached environments that depend on a core that changed."""
-        N = len(self._sites)
-        first, last = None, None
-        for j, st in enumerate(self._sites):
-            t = st.node.tensor
-            seen = d.seen[j]
-            if seen is None or seen[0] is not t or seen[1] != t._version:
-                if first is None:
-                    first = j
-                last = j
-                d.seen[j] = (t, t._version)
-        if first is not None:
-            for k in range(first + 1, N):
-                d.L[k] = None
-            for k in range(0, last):
-                d.R[k] = None
-
-    def _left(self, d, k):
-        """Environment entering site k from the left: (S, C, rl_k)."""
-        if d.L[k] is None:
-            if k == 0:
-                C = self._out_dim()
-                dev = d.xs[0].device
-                d.L[0] = torch.eye(C, dtype=torch.float64, device=dev).unsqueeze(0).expand(d.S, C, C).contiguous()
-            else:
-                d.L[k] = ops.env_step_left(self._left(d, k - 1), d.xs[k - 1], self._canon(k - 1))
-        return d.L[k]
-
-    def _right(self, d, k):
-        """Environment entering site k from the right: (S, rr_k)."""
-        N = len(self._sites)
-        if d.R[k] is None:
-            if k == N - 1:
-                d.R[k] = torch.ones((d.S, 1), dtype=torch.float64, device=d.xs[0].device)
-            else:
-                d.R[k] = ops.env_step_right(self._right(d, k + 1), d.xs[k + 1], self._canon(k + 1))
-        return d.R[k]
+        return self._engine.data_for(x, shard=shard)
 
     def _predict(self, d, k=None):
-        """(S, C) prediction, cut at site k (default: the cheapest cut)."""
-        self._sync(d)
-        N = len(self._sites)
-        if k is None:
-            vl = 0
-            while vl + 1 < N and d.L[vl + 1] is not None:
-                vl += 1
-            vr = N - 1
-            while vr - 1 >= 0 and d.R[vr - 1] is not None:
-                vr -= 1
-            k = min(range(N), key=lambda j: max(0, j - vl) + max(0, vr - j))
-        Lk1 = ops.env_step_left(self._left(d, k), d.xs[k], self._canon(k))
-        return ops.predict(Lk1, self._right(d, k))
+        return self._engine.predict(d, k)
 
     def _shape_output(self, y):
         """(S, C) -> TensorNode labelled like the reference's forward output."""
-        st = self._sites[0]
-        sizes = [st.node.dim_size(lab) for lab in st.out_labels]
-        node = TensorNode(y.reshape([y.shape[0]] + sizes), [self.sample_dim] + list(st.out_labels), name='O')
+        col = self._engine.cols[0]
+        sizes = [col.A.dim_size(lab) for lab in col.out_labels]
+        node = TensorNode(y.reshape([y.shape[0]] + sizes), [self.sample_dim] + list(col.out_labels), name='O')
         if self.output_labels is not None:
             node.permute_first(*self.output_labels)
         return node
@@ -291,13 +104,13 @@ class TensorNetwork:
         d = self._current
         if d is None:
             return
-        self._sync(d)
-        N = len(self._sites)
-        self._left(d, N - 1)
-        self._right(d, 0)
+        eng = self._engine
+        eng.sync(d)
+        eng.left(d, len(eng.cols) - 1)
+        eng.right(d, 0)
 
     def left_update_stacks(self, node):
-        """Environments are refreshed lazily from core identities; nothing to do eagerly."""
+        """Environments are refreshed lazily from node identities; nothing to do eagerly."""
 
     def right_update_stacks(self, node):
         """See left_update_stacks."""
@@ -351,64 +164,100 @@ class TensorNetwork:
         return bool(torch.equal(H, H.transpose(1, 2)))
 
     def _local(self, node):
-        sites = self._require_chain()
+        self._require_chain()
         if self._current is None:
             raise RuntimeError("no input bound: call forward(x) / set_input(x) first")
         d = self._current
-        self._sync(d)
-        k = self.main_nodes.index(node)
-        self._canon(k)
-        return d, k, self._left(d, k), d.xs[k], self._right(d, k)
+        return d, self._engine.local(d, node)
 
-    def _gram_into_ws(self, L, X, R, H):
-        S, C, rl = L.shape
-        sym = self._hessian_symmetric(H)
-        key = (S, C, rl, X.shape[1], R.shape[1], int(sym))
-        ws = self._gram_ws.get(key)
-        if ws is None:
-            self._gram_ws.clear()
-        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
-        self._gram_ws[key] = ws
-        return ws
+    def _gram_matrix(self, lp, H, scale=None, ridge=0.0, out=None):
+        """Dense (D,D) Gram matrix of a local problem, optionally scaled and ridged."""
+        if lp.single_term():
+            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
+            return ops.gram_expand(ws, scale=scale, ridge=ridge, out=out)
+        A = lp.dense_gram(H)
+        if scale is not None:
+            A.div_(scale)
+        if ridge:
+            A.diagonal().add_(ridge)
+        return A
+
+    def _node_axes(self, node, A):
+        """Canonical (D,D) -> node.shape + node.shape in the node's own axis order."""
+        sizes, perm = self._engine.layout(node)
+        A = A.reshape(list(sizes) + list(sizes))
+        inv = [perm.index(a) for a in range(len(perm))]
+        if inv != list(range(len(inv))):
+            n = len(inv)
+            A = A.permute(inv + [n + a for a in inv])
+        return A
 
     @torch.no_grad()
     def get_A_b(self, node, grad, hessian, method=None):
         """Gram matrix (node.shape + node.shape) and right-hand side (node.shape)
         of the local normal equations for the bound input (tensor/network.py:174-217)."""
-        d, k, L, X, R = self._local(node)
-        g, H = self._norm_gh(grad, hessian, d.S, L.shape[1])
-        b = self._from_canon(k, ops.rhs(L, X, R, g))
+        d, lp = self._local(node)
+        g, H = self._norm_gh(grad, hessian, d.S, lp.C)
+        b = lp.back(lp.rhs(g))
         if method is not None:
             return torch.randn((2, 2, 2, 2)), b   # the reference's placeholder for method='gradient'
-        ws = self._gram_into_ws(L, X, R, H)
-        st = self._sites[k]
-        A = ops.gram_expand(ws).reshape(st.sizes + st.sizes)
-        perm = [st.node.dim_labels.index(lab) for lab in st.order]
-        inv = [perm.index(a) for a in range(len(perm))]
-        if inv != list(range(len(inv))):
-            n = len(inv)
-            A = A.permute(inv + [n + a for a in inv])
+        A = self._node_axes(node, self._gram_matrix(lp, H))
         return A.to(node.tensor.dtype), b
 
     @torch.no_grad()
     def get_b(self, node, grad):
-        d, k, L, X, R = self._local(node)
-        g = ops.prep(grad.reshape(d.S, L.shape[1]))
-        return self._from_canon(k, ops.rhs(L, X, R, g))
+        d, lp = self._local(node)
+        return lp.back(lp.rhs(ops.prep(grad.reshape(d.S, lp.C))))
 
     @torch.no_grad()
     def matvec(self, node, v, hessian):
         """(J^T H J) v for the bound input, never forming the Gram matrix
         (the two einsums at tensor/network.py:788-789)."""
-        d, k, L, X, R = self._local(node)
-        st = self._sites[k]
-        H = self._norm_h(hessian, d.S, L.shape[1])
-        perm = [st.node.dim_labels.index(lab) for lab in st.order]
-        vc = ops.prep(v.permute(perm).reshape(st.rl, st.p, st.rr))
-        return self._from_canon(k, ops.matvec(L, X, R, H, vc))
+        d, lp = self._local(node)
+        H = self._norm_h(hessian, d.S, lp.C)
+        return lp.back(lp.matvec_fn(H)(self._engine.to_canon(node, v)))
 
+    @torch.no_grad()
     def get_J(self, node, grad):
-        raise NotImplementedError("the Jacobian is never materialised in this build; use matvec(node, v, hessian)")
+        """Per-sample Jacobian of the output with respect to `node` and the einsum strings that
+        contract it (tensor/network.py:219-256): axes are the output labels the node does not
+        carry (sample first), then the node's own labels; an output label that sits on the node
+        itself appears once, as in the reference.  Materialises S*C*D numbers - the sweep methods
+        of this build never call it; use matvec(node, v, hessian) for products."""
+        import string
+        d, lp = self._local(node)
+        sdim = self.sample_dim
+        sizes, perm = self._engine.layout(node)
+        col0 = self._engine.cols[0]
+        out0 = list(col0.out_labels)
+        J = lp.rows(0, d.S).reshape([d.S] + [col0.A.dim_size(lab) for lab in out0] + list(sizes))
+        no = 1 + len(out0)
+        inv = [perm.index(a) for a in range(len(perm))]
+        J = J.permute(list(range(no)) + [no + a for a in inv])
+        labels = [sdim] + out0 + list(node.dim_labels)
+        for lab in out0:                       # J[s, c, (c', ...)] = delta(c, c') * rest: drop the node-side copy
+            if lab in node.dim_labels:
+                idx = len(labels) - 1 - labels[::-1].index(lab)
+                J = J.sum(dim=idx)
+                del labels[idx]
+        outs_all = list(self.output_labels or (sdim,))
+        Jn = TensorNode(J.to(node.tensor.dtype).contiguous(), labels, name='J')
+        Jn.permute_first(*[lab for lab in outs_all if lab not in node.dim_labels])
+        letters = iter(string.ascii_letters)
+        dl = {lab: next(letters) for lab in outs_all}
+        olf = [lab for lab in outs_all if lab != sdim]
+        for lab in olf:
+            dl['_' + lab] = next(letters)
+        for lab in Jn.dim_labels:
+            if lab not in dl:
+                dl[lab] = next(letters)
+                dl['_' + lab] = next(letters)
+        return {'J': Jn,
+                'einsum': ''.join(dl[lab] for lab in Jn.dim_labels),
+                'node_ein': ''.join(dl[lab] for lab in node.dim_labels),
+                'dd_loss_ein': dl[sdim] + ''.join(dl[lab] for lab in olf) + ''.join(dl['_' + lab] for lab in olf),
+                'd_loss_ein': ''.join(dl[lab] for lab in outs_all),
+                'coeff_ein': dl[sdim] + ''.join(dl['_' + lab] for lab in olf)}
 
     def solve_system(self, node, A, b, method='exact', eps=0.0):
         """Scale by mean |diag|, ridge 2*eps on the scaled system with the unscaled
@@ -434,19 +283,16 @@ class TensorNetwork:
             raise ValueError(f"Unknown method: {method}")
         return x.reshape(b.shape)
 
-    # ------------------------------------------------------------------ one core update on the full data
-    def _site_update(self, d, k, y, loss_fn, batch_size, method, eps_, lr, adaptive_step, min_norm, max_norm,
+    # ------------------------------------------------------------------ one node update on the full data
+    def _site_update(self, d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step, min_norm, max_norm,
                      want_loss):
-        """Gram + RHS over all samples, solve, update core k.  Returns the
+        """Gram + RHS over all samples, solve, update the node.  Returns the
         mean-of-batch-means loss (float, or None if not requested)."""
-        st = self._sites[k]
-        node = st.node
-        self._sync(d)
-        L, X, R = self._left(d, k), d.xs[k], self._right(d, k)
-        core = self._canon(k)
-        y_pred = ops.predict(ops.env_step_left(L, X, core), R)
+        lp = self._engine.local(d, node)
+        core = lp.core
+        y_pred = lp.jv(core)                         # the output is linear in every single node
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
-        g, H = self._norm_gh(grad, hess, d.S, L.shape[1])
+        g, H = self._norm_gh(grad, hess, d.S, lp.C)
         total = self._batch_mean_loss(d, loss, batch_size) if want_loss else None
         m = method.lower()
         if m not in ('exact', 'ridge_exact', 'cholesky') and not m.startswith('ridge_cholesky'):
@@ -454,31 +300,39 @@ class TensorNetwork:
         if eps_ == 0 and m == 'ridge_exact':
             m = 'exact'
         ridged = m == 'ridge_exact' or m.startswith('ridge_cholesky')
-        ws = self._gram_into_ws(L, X, R, H)
-        b = ops.rhs(L, X, R, g)
-        if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
-            self._shard.allreduce_sum_(ws.compressed)
-            self._shard.allreduce_sum_(b)
-        scale = ops.gram_scale(ws)
         ridge = 2 * eps_ if ridged else 0.0
-        if m in ('exact', 'ridge_exact'):
-            D = st.rl * st.p * st.rr
-            buf = self._abuf.get(D)
-            if buf is None:
-                self._abuf.clear()
-                buf = torch.empty((D, D), dtype=torch.float64, device=L.device)
-                self._abuf[D] = buf
-            A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=buf)
-            x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
+        b = lp.rhs(g)
+        if lp.single_term():
+            # compressed symmetric Gram in the workspace, own Cholesky on it
+            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
+            if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
+                self._shard.allreduce_sum_(ws.compressed)
+                self._shard.allreduce_sum_(b)
+            scale = ops.gram_scale(ws)
+            if m in ('exact', 'ridge_exact'):
+                A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=self._engine.dense_buffer(lp.D, b.device))
+                x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
+            else:
+                x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
+                bad = int(info.item())
+                if bad != 0:
+                    raise torch.linalg.LinAlgError(
+                        "linalg.cholesky: The factorization could not be completed because the input is not "
+                        f"positive-definite (the leading minor of order {bad} is not positive-definite).")
         else:
-            x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
-            bad = int(info.item())
-            if bad != 0:
-                raise torch.linalg.LinAlgError(
-                    "linalg.cholesky: The factorization could not be completed because the input is not "
-                    f"positive-definite (the leading minor of order {bad} is not positive-definite).")
-        node.update_node(self._from_canon(k, x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm,
-                         max_norm=max_norm)
+            # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
+            A_f = lp.dense_gram(H)
+            if d.sharded:
+                self._shard.allreduce_sum_(A_f)
+                self._shard.allreduce_sum_(b)
+            scale = A_f.diagonal().abs().mean()
+            scale = torch.where(scale == 0, torch.ones_like(scale), scale)
+            A_f.div_(scale)
+            if ridge:
+                A_f.diagonal().add_(ridge)
+            rhs = ops.solve_rhs(b, core if ridged else None, scale, ridge).reshape(-1)
+            x = torch.linalg.solve(A_f, rhs) if m in ('exact', 'ridge_exact') else _cholesky_solve(A_f, rhs)
+        node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return None if total is None else total.item()
 
     def _batch_mean_loss(self, d, loss, batch_size):
@@ -489,28 +343,25 @@ class TensorNetwork:
             v = self._shard.gather_rows(v, d.S_total)
         return ops.batch_mean(v, batch_size)
 
-    def _gradient_pass(self, d, k, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm, per_batch_update):
-        """method='gradient' (tensor/network.py:458-470): the core moves after every
-        mini-batch in the first direction, so batches are visited one by one."""
-        node = self._sites[k].node
-        S = d.S
+    def _gradient_pass(self, d, node, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm, per_batch_update):
+        """method='gradient' (tensor/network.py:458-470): the node moves after every
+        mini-batch in the first direction, so batches are visited one by one.  The Jacobian
+        of a node does not depend on the node itself, so it is set up once per visit."""
+        lp = self._engine.local(d, node)
         total, b_out, batches = 0.0, None, 0
-        for b0 in range(0, S, batch_size):
-            sl = slice(b0, min(S, b0 + batch_size))
-            self._sync(d)
-            L, X, R = self._left(d, k)[sl].contiguous(), d.xs[k][sl].contiguous(), self._right(d, k)[sl].contiguous()
-            y_pred = ops.predict(ops.env_step_left(L, X, self._canon(k)), R)
-            loss, grad, _ = loss_fn.forward(self._shape_output(y_pred).tensor, y[sl])
-            bv = ops.rhs(L, X, R, ops.prep(grad.reshape(L.shape[0], L.shape[1])))
+        for b0 in range(0, d.S, batch_size):
+            lo, hi = b0, min(d.S, b0 + batch_size)
+            sub = lp.slice(lo, hi)
+            y_pred = sub.jv(self._engine.to_canon(node, node.tensor))
+            loss, grad, _ = loss_fn.forward(self._shape_output(y_pred).tensor, y[lo:hi])
+            bv = sub.rhs(ops.prep(grad.reshape(hi - lo, lp.C)))
             b_out = bv if b_out is None else b_out + bv
             if per_batch_update:
-                node.update_node(self._from_canon(k, bv), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm,
-                                 max_norm=max_norm)
+                node.update_node(lp.back(bv), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
             total += loss.mean().item()
             batches += 1
         if not per_batch_update:
-            node.update_node(self._from_canon(k, -b_out), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm,
-                             max_norm=max_norm)
+            node.update_node(lp.back(-b_out), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return total / batches
 
     def accumulating_swipe(self, x, y_true, loss_fn, node_order=None, batch_size=-1, num_swipes=1, lr=1.0,
@@ -556,13 +407,12 @@ class TensorNetwork:
                 if timeout is not None and (time.time() - start) > timeout:
                     print(f"Timeout reached ({timeout} seconds). Stopping accumulating_swipe.")
                     return False
-                k = self.main_nodes.index(node)
                 try:
                     if method == 'gradient':
-                        loss = self._gradient_pass(d, k, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm,
+                        loss = self._gradient_pass(d, node, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm,
                                                    per_batch_update=(which == "fwd"))
                     else:
-                        loss = self._site_update(d, k, y, loss_fn, batch_size, method, eps_, lr, adaptive_step,
+                        loss = self._site_update(d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step,
                                                  min_norm, max_norm, want_loss)
                 except torch.linalg.LinAlgError:
                     if verbose and verbose > 0:
@@ -654,59 +504,58 @@ class TensorNetwork:
         prev.tensor = torch.einsum('ji,...j->...i', Rm, prev.tensor)
 
     # ------------------------------------------------------------------ matrix-free sweeps
-    def _krylov_setup(self, d, k, y, loss_fn, batch_size, want_loss):
+    def _krylov_setup(self, d, node, y, loss_fn, batch_size, want_loss):
         """RHS phase shared by lanczos_swipe / scipy_swipe (tensor/network.py:746-767)."""
-        self._sync(d)
-        L, X, R = self._left(d, k), d.xs[k], self._right(d, k)
-        core = self._canon(k)
-        y_pred = ops.predict(ops.env_step_left(L, X, core), R)
+        lp = self._engine.local(d, node)
+        y_pred = lp.jv(lp.core)
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
-        g, H = self._norm_gh(grad, hess, d.S, L.shape[1])
-        b = ops.rhs(L, X, R, g)
+        g, H = self._norm_gh(grad, hess, d.S, lp.C)
+        b = lp.rhs(g)
         if d.sharded:
             self._shard.allreduce_sum_(b)
         lossv = self._batch_mean_loss(d, loss, batch_size).item() if want_loss else None
-        return L, X, R, H, b, lossv
+        return lp, H, b, lossv
 
-    def _matvec_fn(self, d, L, X, R, H):
+    def _matvec_fn(self, d, lp, H):
         """v -> (J^T H J) v over all samples; sharded runs add one all-reduce of the
         D-vector per product."""
+        mv = lp.matvec_fn(H)
         if d.sharded:
-            return lambda v: self._shard.allreduce_sum_(ops.matvec(L, X, R, H, v))
-        return lambda v: ops.matvec(L, X, R, H, v)
+            return lambda v: self._shard.allreduce_sum_(mv(v))
+        return mv
 
-    def lanczos_swipe(self, x, y_true, loss_fn, batch_size=1, num_swipes=1, lr=1.0, max_iter=50, tol=1e-6,
-                      verbose=False, timeout=None, data_device=None, model_device=None, disable_tqdm=None,
-                      block_callback=None, loss_callback=None):
-        """Matrix-free Lanczos-Galerkin step per core (tensor/network.py:709-832).
-        The start vector is drawn from the CPU generator (one randn per visited
-        node, in visiting order) so that a seeded run reproduces the reference's CPU path."""
+    def _sweep_data(self, x, y_true, batch_size):
         self._require_chain()
         d = self._data_for(x, shard=self._shard)
         self._current = d
         device = d.xs[0].device
         y = y_true if self._shard is None else self._shard.rows(y_true)
         y = y.to(device) if y.device != device else y
-        if batch_size <= 0:
-            batch_size = d.S_total
+        return d, y, (d.S_total if batch_size <= 0 else batch_size)
+
+    def lanczos_swipe(self, x, y_true, loss_fn, batch_size=1, num_swipes=1, lr=1.0, max_iter=50, tol=1e-6,
+                      verbose=False, timeout=None, data_device=None, model_device=None, disable_tqdm=None,
+                      block_callback=None, loss_callback=None):
+        """Matrix-free Lanczos-Galerkin step per node (tensor/network.py:709-832).
+        The start vector is drawn from the CPU generator (one randn per visited
+        node, in visiting order) so that a seeded run reproduces the reference's CPU path."""
+        d, y, batch_size = self._sweep_data(x, y_true, batch_size)
+        device = d.xs[0].device
         start = time.time() if timeout is not None else None
         for NS in range(num_swipes):
             for node in (self.train_nodes if NS % 2 == 0 else reversed(self.train_nodes)):
                 if timeout is not None and (time.time() - start) > timeout:
                     print(f"Timeout reached ({timeout} seconds). Stopping lanczos_swipe.")
                     return False
-                k = self.main_nodes.index(node)
-                L, X, R, H, b, lossv = self._krylov_setup(d, k, y, loss_fn, batch_size, loss_callback is not None)
+                lp, H, b, lossv = self._krylov_setup(d, node, y, loss_fn, batch_size, loss_callback is not None)
                 if loss_callback is not None:
                     loss_callback(lossv)
                 x0n = torch.randn(tuple(node.tensor.shape), dtype=node.tensor.dtype)
-                st = self._sites[k]
-                perm = [node.dim_labels.index(lab) for lab in st.order]
-                x0 = ops.prep(x0n.to(device).permute(perm).reshape(st.rl, st.p, st.rr))
+                x0 = self._engine.to_canon(node, x0n.to(device))
                 if d.sharded:
                     self._shard.broadcast_(x0)
-                step = lanczos_solve(self._matvec_fn(d, L, X, R, H), -b, x0, max_iter, tol)
-                node.update_node(self._from_canon(k, step), lr=lr)
+                step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol)
+                node.update_node(lp.back(step), lr=lr)
                 if block_callback is not None:
                     block_callback(NS, node)
         return True
@@ -714,18 +563,11 @@ class TensorNetwork:
     def scipy_swipe(self, x, y_true, loss_fn, solver, batch_size=1, num_swipes=1, lr=1.0, max_iter=50, tol=1e-6,
                     verbose=False, timeout=None, data_device=None, model_device=None, disable_tqdm=None,
                     block_callback=None, loss_callback=None):
-        """CG / MINRES step per core (tensor/network.py:834-932).  scipy.sparse.linalg.cg
+        """CG / MINRES step per node (tensor/network.py:834-932).  scipy.sparse.linalg.cg
         and .minres are recognised and run as device-resident float64 iterations with
         SciPy's recurrences and stopping rules; any other callable receives a SciPy
         LinearOperator around the device mat-vec."""
-        self._require_chain()
-        d = self._data_for(x, shard=self._shard)
-        self._current = d
-        device = d.xs[0].device
-        y = y_true if self._shard is None else self._shard.rows(y_true)
-        y = y.to(device) if y.device != device else y
-        if batch_size <= 0:
-            batch_size = d.S_total
+        d, y, batch_size = self._sweep_data(x, y_true, batch_size)
         start = time.time() if timeout is not None else None
         warm = {}
         kind = _scipy_kind(solver)
@@ -734,11 +576,10 @@ class TensorNetwork:
                 if timeout is not None and (time.time() - start) > timeout:
                     print(f"Timeout reached ({timeout} seconds). Stopping lanczos_swipe.")
                     return False
-                k = self.main_nodes.index(node)
-                L, X, R, H, b, lossv = self._krylov_setup(d, k, y, loss_fn, batch_size, loss_callback is not None)
+                lp, H, b, lossv = self._krylov_setup(d, node, y, loss_fn, batch_size, loss_callback is not None)
                 if loss_callback is not None:
                     loss_callback(lossv)
-                mv = self._matvec_fn(d, L, X, R, H)
+                mv = self._matvec_fn(d, lp, H)
                 if kind == 'cg':
                     sol, _ = cg_solve(mv, -b, warm.get(node), max_iter, tol)
                 elif kind == 'minres':
@@ -746,223 +587,10 @@ class TensorNetwork:
                 else:
                     sol = _host_solver(solver, mv, -b, warm.get(node), max_iter, tol)
                 warm[node] = sol
-                node.update_node(self._from_canon(k, sol), lr=lr)
+                node.update_node(lp.back(sol), lr=lr)
                 if block_callback is not None:
                     block_callback(NS, node)
         return True
 
     def disconnect(self, nodes):
         raise NotImplementedError("disconnect() is not part of the core-update path of this build")
-
-
-# ---------------------------------------------------------------------- solvers
-def _cholesky_solve(A_f, rhs):
-    """Cholesky factorisation + two triangular solves; a non-positive pivot raises
-    torch.linalg.LinAlgError like torch.linalg.cholesky in the reference."""
-    Lc, info = torch.linalg.cholesky_ex(A_f)
-    if int(info.item()) != 0:
-        raise torch.linalg.LinAlgError(
-            f"linalg.cholesky: The factorization could not be completed because the input is not positive-definite "
-            f"(the leading minor of order {int(info.item())} is not positive-definite).")
-    return torch.cholesky_solve(rhs.unsqueeze(-1), Lc).squeeze(-1)
-
-
-def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8):
-    """Lanczos-Galerkin without re-orthogonalisation (tensor/network.py:796-824).
-    alpha/beta stay on the device; the beta < tol exit is tested every
-    `check_every` iterations and the basis truncated to the first hit, which gives
-    the same result as leaving the loop at that iteration."""
-    shape = x0.shape
-    r0 = b - matvec(x0)
-    beta1 = ops.dot(r0, r0).sqrt()
-    V = [r0 / beta1]
-    alphas, betas = [], [beta1]
-    v_prev = torch.zeros_like(x0)
-    m = 0
-    for j in range(1, max_iter + 1):
-        w = matvec(V[j - 1])
-        ops.axpy(betas[j - 1], v_prev, w, sign=-1.0)
-        a_j = ops.dot(w, V[j - 1])
-        ops.axpy(a_j, V[j - 1], w, sign=-1.0)
-        bj = ops.dot(w, w).sqrt()
-        alphas.append(a_j)
-        betas.append(bj)
-        v_prev = V[j - 1]
-        V.append(w / bj)
-        m = j
-        if j % check_every == 0 or j == max_iter:
-            small = (torch.stack(betas[1:]) < tol).nonzero()
-            if small.numel() > 0:
-                m = int(small[0].item()) + 1
-                break
-    a = torch.stack(alphas[:m])
-    Tm = torch.diag(a)
-    if m > 1:
-        off = torch.stack(betas[1:m])
-        Tm = Tm + torch.diag(off, diagonal=1) + torch.diag(off, diagonal=-1)
-    rhs = torch.zeros(m, dtype=x0.dtype, device=x0.device)
-    rhs[0] = beta1
-    yv = torch.linalg.solve(Tm, rhs)
-    Vm = torch.stack([v.reshape(-1) for v in V[:m]], dim=-1)
-    return x0 + (Vm @ yv).reshape(shape)
-
-
-def cg_solve(matvec, b, x0, maxiter, rtol):
-    """Conjugate gradients with scipy.sparse.linalg.cg's recurrence and stopping
-    rule (||r|| < max(0, rtol*||b||) tested before each iteration; SciPy 1.15
-    _isolve/iterative.py), in float64 on the device."""
-    bnrm = ops.dot(b, b).sqrt()
-    atol = rtol * bnrm
-    if x0 is None:
-        xk = torch.zeros_like(b)
-        r = b.clone()
-    else:
-        xk = x0.clone()
-        r = b - matvec(xk)
-    p, rho_prev = None, None
-    for it in range(maxiter):
-        rr = ops.dot(r, r)
-        if bool(rr.sqrt() < atol):
-            return xk, 0
-        if it > 0:
-            p = r + (rr / rho_prev) * p
-        else:
-            p = r.clone()
-        q = matvec(p)
-        alpha = rr / ops.dot(p, q)
-        ops.axpy(alpha, p, xk, sign=1.0)
-        ops.axpy(alpha, q, r, sign=-1.0)
-        rho_prev = rr
-    return xk, maxiter
-
-
-def minres_solve(matvec, b, x0, maxiter, rtol):
-    """MINRES (Paige & Saunders) following scipy.sparse.linalg.minres (SciPy 1.15
-    _isolve/minres.py) without shift or preconditioner; scalars live on the host
-    as in SciPy, vectors stay on the device."""
-    import math
-    n = b.numel()
-    eps = torch.finfo(b.dtype).eps
-    xk = torch.zeros_like(b) if x0 is None else x0.clone()
-    r1 = b.clone() if x0 is None else b - matvec(xk)
-    y = r1
-    beta1 = ops.dot(r1, y).item()
-    if beta1 < 0:
-        raise ValueError('indefinite preconditioner')
-    if beta1 == 0:
-        return xk, 0
-    bnorm = ops.dot(b, b).sqrt().item()
-    if bnorm == 0:
-        return b.clone(), 0
-    beta1 = math.sqrt(beta1)
-    oldb, beta, dbar, epsln, qrnorm, phibar, rhs1, rhs2 = 0.0, beta1, 0.0, 0.0, beta1, beta1, beta1, 0.0
-    tnorm2, gmax, gmin = 0.0, 0.0, float(torch.finfo(b.dtype).max)
-    cs, sn = -1.0, 0.0
-    w = torch.zeros_like(b)
-    w2 = torch.zeros_like(b)
-    r2 = r1
-    istop, itn = 0, 0
-    Anorm = Acond = rnorm = ynorm = 0.0
-    while itn < maxiter:
-        itn += 1
-        s = 1.0 / beta
-        v = s * y
-        y = matvec(v)
-        if itn >= 2:
-            y = y - (beta / oldb) * r1
-        alfa = ops.dot(v, y).item()
-        y = y - (alfa / beta) * r2
-        r1 = r2
-        r2 = y
-        oldb = beta
-        beta = ops.dot(r2, y).item()
-        if beta < 0:
-            raise ValueError('non-symmetric matrix')
-        beta = math.sqrt(beta)
-        tnorm2 += alfa ** 2 + oldb ** 2 + beta ** 2
-        if itn == 1:
-            if beta / beta1 <= 10 * eps:
-                istop = -1
-        oldeps = epsln
-        delta = cs * dbar + sn * alfa
-        gbar = sn * dbar - cs * alfa
-        epsln = sn * beta
-        dbar = -cs * beta
-        root = math.hypot(gbar, dbar)
-        Arnorm = phibar * root
-        gamma = max(math.hypot(gbar, beta), eps)
-        cs = gbar / gamma
-        sn = beta / gamma
-        phi = cs * phibar
-        phibar = sn * phibar
-        denom = 1.0 / gamma
-        w1 = w2
-        w2 = w
-        w = (v - oldeps * w1 - delta * w2) * denom
-        xk = xk + phi * w
-        gmax = max(gmax, gamma)
-        gmin = min(gmin, gamma)
-        z = rhs1 / gamma
-        rhs1 = rhs2 - delta * z
-        rhs2 = -epsln * z
-        Anorm = math.sqrt(tnorm2)
-        ynorm = ops.dot(xk, xk).sqrt().item()
-        epsa = Anorm * eps
-        epsx = Anorm * ynorm * eps
-        epsr = Anorm * ynorm * rtol
-        diag = gbar if gbar != 0 else epsa
-        qrnorm = phibar
-        rnorm = qrnorm
-        if ynorm == 0 or Anorm == 0:
-            test1 = float('inf')
-        else:
-            test1 = rnorm / (Anorm * ynorm)
-        if Anorm == 0:
-            test2 = float('inf')
-        else:
-            test2 = root / Anorm
-        Acond = gmax / gmin
-        if istop == 0:
-            t1 = 1 + test1
-            t2 = 1 + test2
-            if t2 <= 1:
-                istop = 2
-            if t1 <= 1:
-                istop = 1
-            if itn >= maxiter:
-                istop = 6
-            if Acond >= 0.1 / eps:
-                istop = 4
-            if epsx >= beta1:
-                istop = 3
-            if test2 <= rtol:
-                istop = 2
-            if test1 <= rtol:
-                istop = 1
-        if istop != 0:
-            break
-    return xk, (maxiter if istop == 6 else 0)
-
-
-def _scipy_kind(solver):
-    mod = getattr(solver, "__module__", "") or ""
-    name = getattr(solver, "__name__", "")
-    if mod.startswith("scipy.sparse.linalg") and name in ("cg", "minres"):
-        return name
-    return None
-
-
-def _host_solver(solver, mv, b, x0, maxiter, rtol):
-    """Unknown solver callables get a SciPy LinearOperator whose mat-vec runs on the
-    device; vectors cross the host boundary as float32 like the reference
-    (tensor/network.py:897,918,921-924)."""
-    from scipy.sparse.linalg import LinearOperator
-    shape, dt, dev = b.shape, b.dtype, b.device
-
-    def host_mv(v):
-        return mv(torch.tensor(v, dtype=dt, device=dev).reshape(shape).contiguous()).flatten().float().cpu().numpy()
-
-    b_np = b.flatten().float().cpu().numpy()
-    op = LinearOperator((b_np.shape[0], b_np.shape[0]), matvec=host_mv)
-    x_sol, _ = solver(op, b_np, x0=None if x0 is None else x0.flatten().float().cpu().numpy(), maxiter=maxiter, rtol=rtol)
-    return torch.tensor(x_sol, dtype=dt, device=dev).reshape(shape)

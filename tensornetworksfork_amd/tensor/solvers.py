@@ -1,0 +1,216 @@
+"""Dense and Krylov solvers of the local systems (reference: tensor/network.py:293-327, 796-824, 897-924)."""
+import torch
+
+from .. import ops
+
+
+def _cholesky_solve(A_f, rhs):
+    """Cholesky factorisation + two triangular solves; a non-positive pivot raises
+    torch.linalg.LinAlgError like torch.linalg.cholesky in the reference."""
+    Lc, info = torch.linalg.cholesky_ex(A_f)
+    if int(info.item()) != 0:
+        raise torch.linalg.LinAlgError(
+            f"linalg.cholesky: The factorization could not be completed because the input is not positive-definite "
+            f"(the leading minor of order {int(info.item())} is not positive-definite).")
+    return torch.cholesky_solve(rhs.unsqueeze(-1), Lc).squeeze(-1)
+
+
+def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8):
+    """Lanczos-Galerkin without re-orthogonalisation (tensor/network.py:796-824).
+    alpha/beta stay on the device; the beta < tol exit is tested every
+    `check_every` iterations and the basis truncated to the first hit, which gives
+    the same result as leaving the loop at that iteration."""
+    shape = x0.shape
+    r0 = b - matvec(x0)
+    beta1 = ops.dot(r0, r0).sqrt()
+    V = [r0 / beta1]
+    alphas, betas = [], [beta1]
+    v_prev = torch.zeros_like(x0)
+    m = 0
+    for j in range(1, max_iter + 1):
+        w = matvec(V[j - 1])
+        ops.axpy(betas[j - 1], v_prev, w, sign=-1.0)
+        a_j = ops.dot(w, V[j - 1])
+        ops.axpy(a_j, V[j - 1], w, sign=-1.0)
+        bj = ops.dot(w, w).sqrt()
+        alphas.append(a_j)
+        betas.append(bj)
+        v_prev = V[j - 1]
+        V.append(w / bj)
+        m = j
+        if j % check_every == 0 or j == max_iter:
+            small = (torch.stack(betas[1:]) < tol).nonzero()
+            if small.numel() > 0:
+                m = int(small[0].item()) + 1
+                break
+    a = torch.stack(alphas[:m])
+    Tm = torch.diag(a)
+    if m > 1:
+        off = torch.stack(betas[1:m])
+        Tm = Tm + torch.diag(off, diagonal=1) + torch.diag(off, diagonal=-1)
+    rhs = torch.zeros(m, dtype=x0.dtype, device=x0.device)
+    rhs[0] = beta1
+    yv = torch.linalg.solve(Tm, rhs)
+    Vm = torch.stack([v.reshape(-1) for v in V[:m]], dim=-1)
+    return x0 + (Vm @ yv).reshape(shape)
+
+
+def cg_solve(matvec, b, x0, maxiter, rtol):
+    """Conjugate gradients with scipy.sparse.linalg.cg's recurrence and stopping
+    rule (||r|| < max(0, rtol*||b||) tested before each iteration; SciPy 1.15
+    _isolve/iterative.py), in float64 on the device."""
+    bnrm = ops.dot(b, b).sqrt()
+    atol = rtol * bnrm
+    if x0 is None:
+        xk = torch.zeros_like(b)
+        r = b.clone()
+    else:
+        xk = x0.clone()
+        r = b - matvec(xk)
+    p, rho_prev = None, None
+    for it in range(maxiter):
+        rr = ops.dot(r, r)
+        if bool(rr.sqrt() < atol):
+            return xk, 0
+        if it > 0:
+            p = r + (rr / rho_prev) * p
+        else:
+            p = r.clone()
+        q = matvec(p)
+        alpha = rr / ops.dot(p, q)
+        ops.axpy(alpha, p, xk, sign=1.0)
+        ops.axpy(alpha, q, r, sign=-1.0)
+        rho_prev = rr
+    return xk, maxiter
+
+
+def minres_solve(matvec, b, x0, maxiter, rtol):
+    """MINRES (Paige & Saunders) following scipy.sparse.linalg.minres (SciPy 1.15
+    _isolve/minres.py) without shift or preconditioner; scalars live on the host
+    as in SciPy, vectors stay on the device."""
+    import math
+    n = b.numel()
+    eps = torch.finfo(b.dtype).eps
+    xk = torch.zeros_like(b) if x0 is None else x0.clone()
+    r1 = b.clone() if x0 is None else b - matvec(xk)
+    y = r1
+    beta1 = ops.dot(r1, y).item()
+    if beta1 < 0:
+        raise ValueError('indefinite preconditioner')
+    if beta1 == 0:
+        return xk, 0
+    bnorm = ops.dot(b, b).sqrt().item()
+    if bnorm == 0:
+        return b.clone(), 0
+    beta1 = math.sqrt(beta1)
+    oldb, beta, dbar, epsln, qrnorm, phibar, rhs1, rhs2 = 0.0, beta1, 0.0, 0.0, beta1, beta1, beta1, 0.0
+    tnorm2, gmax, gmin = 0.0, 0.0, float(torch.finfo(b.dtype).max)
+    cs, sn = -1.0, 0.0
+    w = torch.zeros_like(b)
+    w2 = torch.zeros_like(b)
+    r2 = r1
+    istop, itn = 0, 0
+    Anorm = Acond = rnorm = ynorm = 0.0
+    while itn < maxiter:
+        itn += 1
+        s = 1.0 / beta
+        v = s * y
+        y = matvec(v)
+        if itn >= 2:
+            y = y - (beta / oldb) * r1
+        alfa = ops.dot(v, y).item()
+        y = y - (alfa / beta) * r2
+        r1 = r2
+        r2 = y
+        oldb = beta
+        beta = ops.dot(r2, y).item()
+        if beta < 0:
+            raise ValueError('non-symmetric matrix')
+        beta = math.sqrt(beta)
+        tnorm2 += alfa ** 2 + oldb ** 2 + beta ** 2
+        if itn == 1:
+            if beta / beta1 <= 10 * eps:
+                istop = -1
+        oldeps = epsln
+        delta = cs * dbar + sn * alfa
+        gbar = sn * dbar - cs * alfa
+        epsln = sn * beta
+        dbar = -cs * beta
+        root = math.hypot(gbar, dbar)
+        Arnorm = phibar * root
+        gamma = max(math.hypot(gbar, beta), eps)
+        cs = gbar / gamma
+        sn = beta / gamma
+        phi = cs * phibar
+        phibar = sn * phibar
+        denom = 1.0 / gamma
+        w1 = w2
+        w2 = w
+        w = (v - oldeps * w1 - delta * w2) * denom
+        xk = xk + phi * w
+        gmax = max(gmax, gamma)
+        gmin = min(gmin, gamma)
+        z = rhs1 / gamma
+        rhs1 = rhs2 - delta * z
+        rhs2 = -epsln * z
+        Anorm = math.sqrt(tnorm2)
+        ynorm = ops.dot(xk, xk).sqrt().item()
+        epsa = Anorm * eps
+        epsx = Anorm * ynorm * eps
+        epsr = Anorm * ynorm * rtol
+        diag = gbar if gbar != 0 else epsa
+        qrnorm = phibar
+        rnorm = qrnorm
+        if ynorm == 0 or Anorm == 0:
+            test1 = float('inf')
+        else:
+            test1 = rnorm / (Anorm * ynorm)
+        if Anorm == 0:
+            test2 = float('inf')
+        else:
+            test2 = root / Anorm
+        Acond = gmax / gmin
+        if istop == 0:
+            t1 = 1 + test1
+            t2 = 1 + test2
+            if t2 <= 1:
+                istop = 2
+            if t1 <= 1:
+                istop = 1
+            if itn >= maxiter:
+                istop = 6
+            if Acond >= 0.1 / eps:
+                istop = 4
+            if epsx >= beta1:
+                istop = 3
+            if test2 <= rtol:
+                istop = 2
+            if test1 <= rtol:
+                istop = 1
+        if istop != 0:
+            break
+    return xk, (maxiter if istop == 6 else 0)
+
+
+def _scipy_kind(solver):
+    mod = getattr(solver, "__module__", "") or ""
+    name = getattr(solver, "__name__", "")
+    if mod.startswith("scipy.sparse.linalg") and name in ("cg", "minres"):
+        return name
+    return None
+
+
+def _host_solver(solver, mv, b, x0, maxiter, rtol):
+    """Unknown solver callables get a SciPy LinearOperator whose mat-vec runs on the
+    device; vectors cross the host boundary as float32 like the reference
+    (tensor/network.py:897,918,921-924)."""
+    from scipy.sparse.linalg import LinearOperator
+    shape, dt, dev = b.shape, b.dtype, b.device
+
+    def host_mv(v):
+        return mv(torch.tensor(v, dtype=dt, device=dev).reshape(shape).contiguous()).flatten().float().cpu().numpy()
+
+    b_np = b.flatten().float().cpu().numpy()
+    op = LinearOperator((b_np.shape[0], b_np.shape[0]), matvec=host_mv)
+    x_sol, _ = solver(op, b_np, x0=None if x0 is None else x0.flatten().float().cpu().numpy(), maxiter=maxiter, rtol=rtol)
+    return torch.tensor(x_sol, dtype=dt, device=dev).reshape(shape)

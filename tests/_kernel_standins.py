@@ -1,0 +1,131 @@
+"""TEST INFRASTRUCTURE ONLY: torch-CPU stand-ins for the HIP entry points behind
+tensornetworksfork_amd.ops, installed by the `cpu_kernels` fixture (monkeypatch) so that the
+host-side logic (topology planning, environment caching, sweep schedule, sharding) can be
+exercised on a machine without a GPU.  Nothing in the package imports this module; without the
+fixture every op raises TTKError on CPU tensors."""
+import torch
+
+F64 = torch.float64
+
+
+def env_step_left(E, X, core, out=None):
+    r = torch.einsum('scl,sp,lpr->scr', E, X, core)
+    return r if out is None else out.add_(r)
+
+
+def env_step_right(R, X, core, out=None):
+    r = torch.einsum('sr,sp,lpr->sl', R, X, core)
+    return r if out is None else out.add_(r)
+
+
+def predict(L, R, out=None):
+    r = torch.einsum('scr,sr->sc', L, R)
+    return r if out is None else out.add_(r)
+
+
+def loss(kind, y_pred, y, w=1.0):
+    from oracle import tt_oracle as O
+    lo, g, H = O.loss_xe(y_pred, y, w) if kind == "xe" else O.LOSSES[kind](y_pred, y)
+    S, C = y_pred.shape
+    return lo, g.reshape(S, C).contiguous(), H.reshape(S, C, C).contiguous()
+
+
+def batch_mean(v, batch):
+    S = v.shape[0]
+    means = [v[i:i + batch].mean() for i in range(0, S, batch)]
+    return torch.stack(means).mean()
+
+
+def kr_rows(L, X, R, out=None):
+    S, C, _ = L.shape
+    r = torch.einsum('scl,sp,sr->sclpr', L, X, R).reshape(S, C, -1)
+    return r if out is None else out.add_(r)
+
+
+def hess_left(H, L):
+    return torch.einsum('scd,sdl->scl', H, L)
+
+
+class _WS:
+    def __init__(self, A, dims):
+        self.A = A
+        self.dims = dims
+        self.buf = A
+
+    @property
+    def compressed(self):
+        return self.A
+
+
+def gram(L, H, X, R, sym=True, ws=None):
+    S, C, rl = L.shape
+    J = kr_rows(L, X, R)
+    A = torch.einsum('scd,sce,sef->df', J, H, J)
+    return _WS(A.contiguous(), (S, C, rl, X.shape[1], R.shape[1], int(bool(sym))))
+
+
+def gram_scale(ws):
+    s = ws.A.diagonal().abs().mean()
+    return torch.where(s == 0, torch.ones_like(s), s)
+
+
+def gram_expand(ws, scale=None, ridge=0.0, out=None):
+    A = ws.A if scale is None else ws.A / scale
+    A = A + ridge * torch.eye(A.shape[0], dtype=F64)
+    if out is not None:
+        out.copy_(A)
+        return out
+    return A
+
+
+def rhs(L, X, R, g, out=None):
+    r = torch.einsum('sc,scl,sp,sr->lpr', g, L, X, R)
+    return r if out is None else out.add_(r)
+
+
+def jvp(L, X, R, H, v):
+    u = torch.einsum('scl,sp,sr,lpr->sc', L, X, R, v)
+    return torch.einsum('scd,sd->sc', H, u)
+
+
+def matvec(L, X, R, H, v):
+    return rhs(L, X, R, jvp(L, X, R, H, v))
+
+
+def solve_rhs(b, w=None, scale=None, ridge=0.0):
+    r = b.reshape(-1) if scale is None else b.reshape(-1) / scale
+    if w is not None:
+        r = r + ridge * w.reshape(-1)
+    return -r
+
+
+def chol_solve_gram(ws, b, w=None, scale=None, ridge=0.0):
+    A = gram_expand(ws, scale, ridge)
+    Lc, info = torch.linalg.cholesky_ex(A)
+    if int(info) != 0:
+        return torch.zeros(A.shape[0], dtype=F64), info.to(torch.int32)
+    x = torch.cholesky_solve(solve_rhs(b, w, scale, ridge).unsqueeze(-1), Lc).squeeze(-1)
+    return x, info.to(torch.int32)
+
+
+def qr(A):
+    return torch.linalg.qr(A, mode='reduced')
+
+
+def dot(x, y):
+    return (x * y).sum()
+
+
+def axpy(a, x, y, sign=1.0):
+    return y.add_(sign * a * x)
+
+
+NAMES = ("env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
+         "matvec solve_rhs chol_solve_gram qr dot axpy").split()
+
+
+def install(monkeypatch):
+    from tensornetworksfork_amd import ops
+    g = globals()
+    for n in NAMES:
+        monkeypatch.setattr(ops, n, g[n])

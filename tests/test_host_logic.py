@@ -41,7 +41,7 @@ def test_seeded_layers_match_reference_cores(name):
     layer = TensorTrainLayer(int(d["N"]), int(d["r"]), int(d["p"]), output_shape=int(d["C"]), constrict_bond=cb,
                              seed=int(d["seed"]))
     tn = layer.tensor_network
-    assert tn._sites is not None, tn._chain_error
+    assert tn._engine.cols is not None, tn._engine.error
     for n, c in zip(tn.main_nodes, G.cores(d)):
         assert tuple(n.tensor.shape) == tuple(c.shape) and torch.equal(n.tensor, c)
     assert list(tn.output_labels) == ['s', 'c1']
