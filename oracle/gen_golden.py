@@ -267,7 +267,7 @@ def gen_qr(tag, N, p, r, C, seed):
     npz(f"qr_gauge_{tag}", **d)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_BASE", "1") == "1":
     gen_core_update("n4p3r4c1_sq", 4, 3, 4, 1, 96, "square", True, True, 1)
     gen_core_update("n5p4r6c3_sq", 5, 4, 6, 3, 96, "square", True, True, 2)
     gen_core_update("n4p3r4c3_mse", 4, 3, 4, 3, 96, "mse", True, True, 3)
@@ -366,10 +366,97 @@ def gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind="xe"):
     npz(f"conv_tt_{tag}", **d)
 
 
+# ---------------------------------------------------------------- 7. other topologies on the same path
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests._net_cases import NET_CASES, net_builders as _net_builders  # noqa: E402
+
+
+def gen_net(case, S=72, features=6):
+    kind, C = NET_CASES[case]
+    seed = 200 + sorted(NET_CASES).index(case)
+    build = _net_builders(layers, network)[case]
+    torch.manual_seed(seed)          # CumSumLayer does not seed itself
+    layer = build()
+    tn = layer.tensor_network
+    g = torch.Generator().manual_seed(seed + 100)
+    x = torch.rand(S, features, generator=g) * 2 - 1
+    x[:, -1] = 1.0                   # bias column, as the estimators append it
+    if kind == "xe":
+        y = torch.nn.functional.one_hot(torch.randint(0, C + 1, (S,), generator=g), C + 1).to(torch.float64)
+    else:
+        y = torch.randn(S, C, generator=g)
+    d = {"case": np.array(case), "S": S, "features": features, "C": C, "seed": seed, "x": x, "y": y,
+         "loss_kind": np.array(kind), "train_names": np.array([n.name for n in tn.train_nodes])}
+    for i, t in enumerate(_snap_train(tn)):
+        d[f"node{i}"] = t
+    loss_fn = make_loss(kind)
+    y_pred = tn.forward(x, to_tensor=True)
+    loss, gr, H = loss_fn.forward(y_pred, y)
+    d["y_pred"], d["loss"], d["g"], d["H"] = y_pred, loss, gr, H
+    v_gen = torch.Generator().manual_seed(seed + 7)
+    has_Av = 1
+    for k, node in enumerate(tn.train_nodes):
+        A, b = tn.get_A_b(node, gr, H)
+        d[f"A{k}"], d[f"b{k}"] = A, b
+        v = torch.randn(node.tensor.shape, generator=v_gen)
+        d[f"v{k}"] = v
+        try:
+            pj = tn.get_J(node, gr)
+            coeff = torch.einsum(f"{pj['einsum']},{pj['node_ein']},{pj['dd_loss_ein']}->{pj['coeff_ein']}", pj['J'].tensor, v, H)
+            d[f"Av{k}"] = torch.einsum(f"{pj['einsum']},{pj['d_loss_ein']}->{pj['node_ein']}", pj['J'].tensor, coeff)
+        except Exception as e:       # the reference's get_J does not cover every network class
+            has_Av = 0
+            d["Av_error"] = np.array(f"{type(e).__name__}: {e}"[:200])
+    d["has_Av"] = has_Av
+    for which in ("chol", "lanczos"):
+        torch.manual_seed(seed)
+        tn2 = build().tensor_network
+        snaps, losses = [], []
+        try:
+            if which == "chol":
+                ok = tn2.accumulating_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=2, method="ridge_cholesky",
+                                            eps=1.0, eps_decay=0.5, loss_callback=lambda NS, n, l: losses.append(l),
+                                            block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+            else:
+                torch.manual_seed(seed + 5)
+                ok = tn2.lanczos_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=1, max_iter=5, tol=1e-6,
+                                       loss_callback=lambda l: losses.append(l),
+                                       block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+        except Exception as e:
+            d[f"{which}_error"] = np.array(f"{type(e).__name__}: {e}"[:200])
+            d[f"has_{which}"] = 0
+            continue
+        d[f"has_{which}"] = 1
+        d[f"{which}_ok"] = int(ok)
+        d[f"{which}_losses"] = np.array(losses)
+        d[f"{which}_num_updates"] = len(snaps)
+        for u, snap in enumerate(snaps):
+            for i, t in enumerate(snap):
+                d[f"{which}_u{u}_node{i}"] = t
+    d["lanczos_torch_seed"] = seed + 5
+    npz(f"net_{case}", **d)
+    print(case, "has_Av", has_Av, "chol", d.get("has_chol"), d.get("chol_error"), "lanczos", d.get("has_lanczos"),
+          d.get("lanczos_error"), d.get("Av_error"))
+
+
 def gen_extra():
-    gen_conv("cbm1", 3, 10, 5, 4, -1, 3, 64, 41)
-    gen_conv("cb2", 3, 10, 5, 4, 2, 3, 64, 42)
-    gen_conv("cb2_sq_c1", 3, 6, 4, 3, 2, 1, 48, 43, kind="square")
+    if os.environ.get("TTK_GOLDEN_CONV", "1") == "1":
+        gen_conv("cbm1", 3, 10, 5, 4, -1, 3, 64, 41)
+        gen_conv("cb2", 3, 10, 5, 4, 2, 3, 64, 42)
+        gen_conv("cb2_sq_c1", 3, 6, 4, 3, 2, 1, 48, 43, kind="square")
+    if os.environ.get("TTK_GOLDEN_NETS", "1") == "1":
+        for case in NET_CASES:
+            gen_net(case)
+    # estimator level, every model_type family (models/tensor_train.py:133-208)
+    common = dict(N=3, r=4, output_dim=1, early_stopping=4, num_swipes=2, batch_size=100)
+    gen_ttreg("type1_n3r4", 6, "regression", model_type="tt_type1", **common)
+    gen_ttreg("cpd_n3r4", 7, "regression", model_type="cpd", **common)
+    gen_ttreg("cpd_type1_n3r4", 8, "regression", model_type="cpd_type1", **common)
+    gen_ttreg("cumsum_n3r4", 9, "regression", model_type="tt", cum_sum=True, **common)
+    gen_ttreg("linear_n3r4", 10, "regression", model_type="tt", linear_dim=3, **common)
+    gen_ttreg("linear_type1_ops_n3r4", 11, "regression", model_type="tt_type1", linear_dim=3, train_operator=True, **common)
+    gen_ttreg("iris_cpd_type1", 12, "classification", model_type="cpd_type1", N=3, r=4, output_dim=2, early_stopping=6,
+              num_swipes=3, batch_size=512)
 
 
 if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_EXTRA", "1") == "1":

@@ -6,7 +6,9 @@ from sklearn.base import BaseEstimator, RegressorMixin
 from sklearn.metrics import accuracy_score, r2_score
 
 from ..tensor.bregman import SquareBregFunction
-from ..tensor.layers import TensorTrainLayer
+from ..tensor.layers import (CPDLayer, CumSumLayer, TensorNetworkLayer, TensorTrainLayer,
+                             TensorTrainLinearLayer)
+from ..tensor.network import SumOfNetworks
 from ._common import (EarlyStopping, error_rate_torch, root_mean_squared_error_torch, split_train_val, to_tensor64,
                       unexplained_variance)
 
@@ -47,19 +49,36 @@ class TensorTrainRegressor(BaseEstimator, RegressorMixin):
             raise ValueError("perturb not supported for output dim > 1")
 
     def _initialize_model(self):
-        """Plain 'tt' is the model on the HIP path; the reference's other model_type
-        values (cpd, type-I sums, cum_sum, linear_dim; models/tensor_train.py:138-208)
-        select topologies this build does not carry yet."""
+        """model_type -> topology (models/tensor_train.py:133-208): 'tt*' / 'cpd*' pick the tensor
+        train or the CPD model, '*type1*' / '*typeI*' the sum of models of order 1..N (the
+        higher orders without the bias feature, seeds seed+i), cum_sum the cumulative-sum
+        operator, linear_dim < input_dim a learned linear map per site."""
         if self.input_dim is None:
             raise ValueError("input_dim must be set")
-        plain = (self.model_type.startswith('tt') and 'type1' not in self.model_type and 'typeI' not in self.model_type
-                 and not self.cum_sum and (self.linear_dim is None or self.linear_dim >= self.input_dim))
-        if not plain:
-            raise NotImplementedError(f"model_type={self.model_type!r} (cum_sum={self.cum_sum}, linear_dim="
-                                      f"{self.linear_dim}) is not available in this build; use model_type='tt'")
-        self._model = TensorTrainLayer(self.N, self.r, self.input_dim, output_shape=self.output_dim,
-                                       constrict_bond=self.constrict_bond, perturb=self.perturb,
-                                       seed=self.seed).to(self.device)
+        if isinstance(self.linear_dim, float) and 0 < self.linear_dim < 1:
+            self.linear_dim = max(int(self.linear_dim * self.input_dim), 1)
+        mt = self.model_type
+        type1 = 'type1' in mt or 'typeI' in mt
+        tt_kw = dict(output_shape=self.output_dim, constrict_bond=self.constrict_bond, perturb=self.perturb)
+
+        def make(order, features, seed):
+            if mt.startswith('cpd'):
+                return CPDLayer(order, self.r, features, output_shape=self.output_dim, perturb=self.perturb, seed=seed)
+            if self.cum_sum:
+                return CumSumLayer(order, self.r, features, seed=seed, **tt_kw)
+            if self.linear_dim is None or self.linear_dim >= self.input_dim:
+                return TensorTrainLayer(order, self.r, features, seed=seed, **tt_kw)
+            return TensorTrainLinearLayer(order, self.r, features, self.linear_dim, seed=seed, **tt_kw)
+
+        if not (mt.startswith('cpd') or mt.startswith('tt')):
+            return
+        if type1:
+            nets = [make(i, self.input_dim - 1 if i != 1 else self.input_dim, self.seed + i).tensor_network
+                    for i in range(1, self.N + 1)]
+            self._model = TensorNetworkLayer(SumOfNetworks(nets, output_labels=nets[0].output_labels,
+                                                           train_operators=self.train_operator)).to(self.device)
+        else:
+            self._model = make(self.N, self.input_dim, self.seed).to(self.device)
         if self.verbose > 2:
             print("Number of parameters:", self._model.num_parameters())
 

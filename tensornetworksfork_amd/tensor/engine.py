@@ -1,16 +1,18 @@
 """Chain engine: the arithmetic behind TensorNetwork for tensor-train shaped graphs.
 
-Two column shapes are recognised (one column = one site of the train):
+Three column shapes are recognised (one column = one site of the train):
 
-  plain      A_k (rl,[c],p,rr)  --p--  X_k (S,p)                       tensor/layers.py:194-221
-  conv       A_k (rl,[c],patches,rr) --patches-- X_k (S,patches,pixels) --pixels-- C_k ([a],pixels,[b])
-                                                                       tensor/layers.py:791-890
+  plain     A_k (rl,[c],p,rr) --p-- X_k (S,p)                                   tensor/layers.py:194-221
+  conv      A_k (rl,[c],patches,rr) --patches-- X_k (S,patches,pixels) --pixels-- F_k ([a],pixels,[b])
+                                                                                tensor/layers.py:791-890
+  operator  A_k (rl,[c],u,rr) --u-- F_k ([a],u,d,[b]) --d-- X_k (S,d)           tensor/layers.py:308-343,425-477
+            (a linear map per site, or one site of a matrix-product operator such as the cumulative sum)
 
-A conv column is a plain column whose feature vector depends on the sample through the conv
-node: G_k[a,b][s,patch] = sum_x X_k[s,patch,x] C_k[a,x,b]; with a conv bond (a,b) the
-environments carry the composite bond (r,b) and every contraction of the plain train becomes a
-sum over (a,b) of the same Khatri-Rao kernels (accumulating launches).  A plain column is the
-special case a = b = 1 with G = X.
+A conv / operator column is a plain column whose feature vector depends on the sample through
+the feature node F_k: G_k[a,b][s,:] = X_k[s] . F_k[a,.,b]; with a bond (a,b) between the
+feature nodes the environments carry the composite bond (r,b) and every contraction of the
+plain train becomes a sum over (a,b) of the same Khatri-Rao kernels (accumulating launches).
+A plain column is the special case a = b = 1 with G = X.
 
 Per-sample environments of a whole data set stay resident on the device (`_Data`) and are
 dropped only where a node of an earlier / later column changed.
@@ -23,8 +25,8 @@ F64 = torch.float64
 
 
 class _Column:
-    __slots__ = ("A", "Cn", "xin", "order", "nleft", "out_labels", "sizes", "rl", "p", "rr",
-                 "c_order", "c_sizes", "ca", "cb", "px")
+    __slots__ = ("A", "F", "kind", "xin", "order", "nleft", "out_labels", "sizes", "rl", "p", "rr",
+                 "f_order", "f_nleft", "f_sizes", "ca", "cb", "inner")
 
 
 class _Data:
@@ -39,8 +41,8 @@ class _Data:
         self.L = [None] * N
         self.R = [None] * N
         self.G = [None] * N
-        self.seenA = [None] * N    # (tensor, version) of A_k / C_k when the caches were last valid
-        self.seenC = [None] * N
+        self.seenA = [None] * N    # (tensor, version) of A_k / F_k when the caches were last valid
+        self.seenF = [None] * N
 
     def matches(self, raw):
         return len(raw) == len(self.raw) and all(a is b for a, b in zip(raw, self.raw))
@@ -145,24 +147,69 @@ class LocalProblem:
         return A
 
 
-class ChainEngine:
+class EngineBase:
+    """Shared plumbing of the engines behind TensorNetwork: data-set cache and solver workspaces."""
+
     def __init__(self, net):
         self.net = net
         self.error = None
+        self.datasets = []
+        self._gram_ws = {}
+        self._abuf = {}
+
+    def data_for(self, x, shard=None):
+        raw = self.site_list(x)
+        for d in self.datasets:
+            if d.matches(raw) and d.sharded == (shard is not None):
+                self.datasets.remove(d)
+                self.datasets.append(d)
+                return d
+        d = self.make_data(raw, shard)
+        self.datasets.append(d)
+        if len(self.datasets) > 3:
+            self.datasets.pop(0)
+        return d
+
+    def output_at(self, d, node, lp, core=None, rows=None):
+        """(S, C) prediction through the local problem of `node` (the output is linear in every
+        node); `rows` names the sample range a sliced problem covers."""
+        return lp.jv(lp.core if core is None else core)
+
+    # -- Gram + solve workspaces
+    def gram_ws(self, lp, H, sym):
+        L, X, R = lp.terms[0]
+        key = (lp.S, lp.C, L.shape[2], X.shape[1], R.shape[1], int(sym))
+        ws = self._gram_ws.get(key)
+        if ws is None:
+            self._gram_ws.clear()
+        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
+        self._gram_ws[key] = ws
+        return ws
+
+    def dense_buffer(self, D, device):
+        buf = self._abuf.get(D)
+        if buf is None:
+            self._abuf.clear()
+            buf = torch.empty((D, D), dtype=F64, device=device)
+            self._abuf[D] = buf
+        return buf
+
+
+class ChainEngine(EngineBase):
+    def __init__(self, net):
+        super().__init__(net)
         self.cols = None
         try:
             self.cols = self._plan()
         except ValueError as e:
             self.error = str(e)
-        self.datasets = []
-        self._gram_ws = {}
-        self._abuf = {}
 
     # ------------------------------------------------------------------ topology
     def _plan(self):
         net = self.net
         N = len(net.main_nodes)
-        outs = [lab for lab in (net.output_labels or ()) if lab != net.sample_dim]
+        s = net.sample_dim
+        outs = [lab for lab in (net.output_labels or ()) if lab != s]
         if len(net.input_nodes) != N:
             raise ValueError("expected one input node per core")
         cols = []
@@ -171,11 +218,9 @@ class ChainEngine:
             col = _Column()
             col.A = node
             phys = [(lab, o) for lab, o in node.connections.items() if not node.is_horizontal_bond(lab)]
-            if len(phys) != 1 or phys[0][1] not in net.input_nodes:
-                raise ValueError(f"{node.name}: expected exactly one input edge")
-            plab, xin = phys[0]
-            col.xin = net.input_nodes.index(xin)
-            used.update([node, xin])
+            if len(phys) != 1:
+                raise ValueError(f"{node.name}: expected exactly one vertical edge")
+            plab, below = phys[0]
             left = [lab for lab in node.left_labels if lab in node.dim_labels]
             right = [lab for lab in node.right_labels if lab in node.dim_labels]
             col.out_labels = [lab for lab in node.dim_labels if lab in outs]
@@ -189,25 +234,44 @@ class ChainEngine:
             col.nleft = len(left) + len(col.out_labels)
             if sorted(col.order) != sorted(node.dim_labels):
                 raise ValueError(f"{node.name}: unexpected labels {node.dim_labels}")
-            # input node: (s, p) plain, or (s, patches, pixels) with a conv node on `pixels`
-            xl = list(xin.dim_labels)
-            others = [(lab, o) for lab, o in xin.connections.items() if o is not node]
-            if xl == [net.sample_dim, plab] and not others:
-                col.Cn = None
-                col.c_order = None
-            elif len(xl) == 3 and xl[0] == net.sample_dim and xl[1] == plab and len(others) == 1 and others[0][0] == xl[2]:
-                cn = others[0][1]
-                col.Cn = cn
-                used.add(cn)
-                cl = [lab for lab in cn.left_labels if lab in cn.dim_labels]
-                cr = [lab for lab in cn.right_labels if lab in cn.dim_labels]
-                col.c_order = cl + [xl[2]] + cr
-                if sorted(col.c_order) != sorted(cn.dim_labels) or len(cl) > 1 or len(cr) > 1:
-                    raise ValueError(f"{cn.name}: unexpected labels {cn.dim_labels}")
-                if cl and (i == 0 or cn.connections.get(cl[0]) is not cols[i - 1].Cn):
-                    raise ValueError(f"{cn.name}: left conv bond does not reach the previous conv node")
+            col.F, col.f_order = None, None
+            if below in net.input_nodes:
+                xin = below
+                xl = list(xin.dim_labels)
+                others = [(lab, o) for lab, o in xin.connections.items() if o is not node]
+                if xl == [s, plab] and not others:
+                    col.kind = "plain"
+                elif len(xl) == 3 and xl[0] == s and xl[1] == plab and len(others) == 1 and others[0][0] == xl[2]:
+                    col.kind = "conv"
+                    col.F = others[0][1]
+                    inner = [xl[2]]
+                else:
+                    raise ValueError(f"{xin.name}: unsupported input column {xl}")
             else:
-                raise ValueError(f"{xin.name}: unsupported input column {xl}")
+                col.kind = "op"
+                col.F = below
+                down = [(lab, o) for lab, o in below.connections.items()
+                        if o is not node and not below.is_horizontal_bond(lab)]
+                if len(down) != 1 or down[0][1] not in net.input_nodes:
+                    raise ValueError(f"{below.name}: expected exactly one input edge below the operator node")
+                dlab, xin = down[0]
+                if list(xin.dim_labels) != [s, dlab] or len(xin.connections) != 1:
+                    raise ValueError(f"{xin.name}: expected labels [sample, {dlab}]")
+                inner = [plab, dlab]
+            col.xin = net.input_nodes.index(xin)
+            used.update([node, xin])
+            if col.F is not None:
+                fn = col.F
+                used.add(fn)
+                fl = [lab for lab in fn.left_labels if lab in fn.dim_labels]
+                fr = [lab for lab in fn.right_labels if lab in fn.dim_labels]
+                col.f_order, col.f_nleft = fl + inner + fr, len(fl)
+                if sorted(col.f_order) != sorted(fn.dim_labels) or len(fl) > 1 or len(fr) > 1:
+                    raise ValueError(f"{fn.name}: unexpected labels {fn.dim_labels}")
+                if fl and (i == 0 or fn.connections.get(fl[0]) is not cols[i - 1].F):
+                    raise ValueError(f"{fn.name}: left bond does not reach the previous column's feature node")
+                if fr and (i == N - 1 or fn.connections.get(fr[0]) is None):
+                    raise ValueError(f"{fn.name}: dangling right bond")
             cols.append(col)
         if len(used) != len(net.nodes):
             raise ValueError("nodes outside the recognised columns")
@@ -219,15 +283,42 @@ class ChainEngine:
 
     def require(self):
         if self.cols is None:
-            raise NotImplementedError("this build runs tensor-train shaped networks (plain or conv-featurised "
-                                      f"columns) on the HIP path; topology not recognised: {self.error}")
+            raise NotImplementedError("this build runs tensor-train shaped networks (plain, conv-featurised or "
+                                      f"operator columns) on the HIP path; topology not recognised: {self.error}")
         return self.cols
 
+    # ------------------------------------------------------------------ output layout
+    def out_labels(self):
+        return list(self.cols[0].out_labels)
+
+    def out_sizes(self):
+        col = self.cols[0]
+        return [col.A.dim_size(lab) for lab in col.out_labels]
+
+    def out_dim(self):
+        C = 1
+        for n in self.out_sizes():
+            C *= n
+        return C
+
     # ------------------------------------------------------------------ canonical views
+    @staticmethod
+    def _perm(node, order):
+        return [node.dim_labels.index(lab) for lab in order]
+
+    @staticmethod
+    def _back(node, order, sizes, t):
+        perm = [node.dim_labels.index(lab) for lab in order]
+        t = t.reshape(sizes)
+        inv = [perm.index(a) for a in range(len(perm))]
+        if inv != list(range(len(inv))):
+            t = t.permute(inv)
+        return t.to(node.tensor.dtype)
+
     def canonA(self, k):
         col = self.cols[k]
         node = col.A
-        perm = [node.dim_labels.index(lab) for lab in col.order]
+        perm = self._perm(node, col.order)
         t = node.tensor.permute(perm) if perm != list(range(len(perm))) else node.tensor
         sizes = list(t.shape)
         rl = 1
@@ -239,71 +330,55 @@ class ChainEngine:
         col.sizes, col.rl, col.p, col.rr = sizes, rl, sizes[col.nleft], rr
         return ops.prep(t.reshape(rl, col.p, rr))
 
-    def backA(self, k, t):
+    def canonF(self, k):
+        """(ca, *inner, cb) view of the feature node of column k: inner = (pixels,) for a conv
+        filter, (u, d) for an operator / linear node."""
         col = self.cols[k]
-        node = col.A
-        perm = [node.dim_labels.index(lab) for lab in col.order]
-        t = t.reshape(col.sizes)
-        inv = [perm.index(a) for a in range(len(perm))]
-        if inv != list(range(len(inv))):
-            t = t.permute(inv)
-        return t.to(node.tensor.dtype)
-
-    def permA(self, k):
-        col = self.cols[k]
-        return [col.A.dim_labels.index(lab) for lab in col.order]
-
-    def canonC(self, k):
-        """(ca, pixels, cb) view of the conv node of column k."""
-        col = self.cols[k]
-        cn = col.Cn
-        perm = [cn.dim_labels.index(lab) for lab in col.c_order]
-        t = cn.tensor.permute(perm) if perm != list(range(len(perm))) else cn.tensor
+        fn = col.F
+        perm = self._perm(fn, col.f_order)
+        t = fn.tensor.permute(perm) if perm != list(range(len(perm))) else fn.tensor
         sizes = list(t.shape)
-        nl = len([lab for lab in cn.left_labels if lab in cn.dim_labels])
-        ca = sizes[0] if nl else 1
-        px = sizes[nl]
-        cb = sizes[nl + 1] if len(sizes) > nl + 1 else 1
-        col.c_sizes, col.ca, col.px, col.cb = sizes, ca, px, cb
-        return ops.prep(t.reshape(ca, px, cb))
-
-    def backC(self, k, t):
-        col = self.cols[k]
-        cn = col.Cn
-        perm = [cn.dim_labels.index(lab) for lab in col.c_order]
-        t = t.reshape(col.c_sizes)
-        inv = [perm.index(a) for a in range(len(perm))]
-        if inv != list(range(len(inv))):
-            t = t.permute(inv)
-        return t.to(cn.tensor.dtype)
-
-    def permC(self, k):
-        col = self.cols[k]
-        return [col.Cn.dim_labels.index(lab) for lab in col.c_order]
-
-    def layout(self, node):
-        """(canonical multi-axis sizes, permutation node axes -> canonical axes) of a train node."""
-        k, kind = self.column_of(node)
-        if kind == "A":
-            self.canonA(k)
-            return self.cols[k].sizes, self.permA(k)
-        self.canonC(k)
-        return self.cols[k].c_sizes, self.permC(k)
-
-    def out_dim(self):
-        col = self.cols[0]
-        C = 1
-        for lab in col.out_labels:
-            C *= col.A.dim_size(lab)
-        return C
+        nl = col.f_nleft
+        ni = 1 if col.kind == "conv" else 2
+        col.f_sizes = sizes
+        col.ca = sizes[0] if nl else 1
+        col.inner = tuple(sizes[nl:nl + ni])
+        col.cb = sizes[nl + ni] if len(sizes) > nl + ni else 1
+        return ops.prep(t.reshape((col.ca,) + col.inner + (col.cb,)))
 
     def column_of(self, node):
         for k, col in enumerate(self.cols):
             if node is col.A:
                 return k, "A"
-            if node is col.Cn:
-                return k, "C"
+            if node is col.F:
+                return k, "F"
         raise ValueError("node is not a trainable node of this network")
+
+    def layout(self, node):
+        """(canonical multi-axis sizes, permutation node axes -> canonical axes) of a train node."""
+        k, kind = self.column_of(node)
+        col = self.cols[k]
+        if kind == "A":
+            self.canonA(k)
+            return col.sizes, self._perm(node, col.order)
+        self.canonF(k)
+        return col.f_sizes, self._perm(node, col.f_order)
+
+    def to_canon(self, node, v):
+        k, kind = self.column_of(node)
+        col = self.cols[k]
+        if kind == "A":
+            self.canonA(k)
+            return ops.prep(v.permute(self._perm(node, col.order)).reshape(col.rl, col.p, col.rr))
+        self.canonF(k)
+        return ops.prep(v.permute(self._perm(node, col.f_order)).reshape((col.ca,) + col.inner + (col.cb,)))
+
+    def from_canon(self, node, t):
+        k, kind = self.column_of(node)
+        col = self.cols[k]
+        if kind == "A":
+            return self._back(node, col.order, col.sizes, t)
+        return self._back(node, col.f_order, col.f_sizes, t)
 
     # ------------------------------------------------------------------ data sets
     def site_list(self, x):
@@ -311,20 +386,14 @@ class ChainEngine:
         per_input = list(x) if isinstance(x, (tuple, list)) else [x] * len(self.net.input_nodes)
         return [per_input[col.xin] for col in cols]
 
-    def data_for(self, x, shard=None):
-        raw = self.site_list(x)
-        for d in self.datasets:
-            if d.matches(raw) and d.sharded == (shard is not None):
-                self.datasets.remove(d)
-                self.datasets.append(d)
-                return d
+    def make_data(self, raw, shard=None):
         device = self.net.main_nodes[0].tensor.device
         done, xs = {}, []
         for col, t in zip(self.cols, raw):
             if id(t) not in done:
                 tt = t if shard is None else shard.rows(t)
                 tt = tt.to(device) if tt.device != device else tt
-                want = 2 if col.Cn is None else 3
+                want = 3 if col.kind == "conv" else 2
                 if tt.ndim != want:
                     raise ValueError(f"expected a {want}-d input (samples, features{', pixels' if want == 3 else ''}), "
                                      f"got shape {tuple(tt.shape)}")
@@ -333,9 +402,6 @@ class ChainEngine:
         d = _Data(raw, xs, len(raw))
         d.sharded = shard is not None
         d.S_total = raw[0].shape[0]
-        self.datasets.append(d)
-        if len(self.datasets) > 3:
-            self.datasets.pop(0)
         return d
 
     def sync(self, d):
@@ -343,13 +409,13 @@ class ChainEngine:
         N = len(self.cols)
         first, last = None, None
         for j, col in enumerate(self.cols):
-            ca, cc = _changed(d.seenA[j], col.A), _changed(d.seenC[j], col.Cn)
-            if cc:
+            ca, cf = _changed(d.seenA[j], col.A), _changed(d.seenF[j], col.F)
+            if cf:
                 d.G[j] = None
-                d.seenC[j] = (col.Cn.tensor, col.Cn.tensor._version)
+                d.seenF[j] = (col.F.tensor, col.F.tensor._version)
             if ca:
                 d.seenA[j] = (col.A.tensor, col.A.tensor._version)
-            if ca or cc:
+            if ca or cf:
                 first = j if first is None else first
                 last = j
         if first is not None:
@@ -360,17 +426,23 @@ class ChainEngine:
 
     # ------------------------------------------------------------------ features and environments
     def feats(self, d, k):
-        """G_k: (ca, cb, S, p) feature vectors per conv-bond pair (a plain column: X itself)."""
+        """G_k: (ca, cb, S, p) feature vectors per feature-bond pair (a plain column: X itself).
+        The product with the feature node is one plain library GEMM."""
         if d.G[k] is None:
             col = self.cols[k]
             X = d.xs[k]
-            if col.Cn is None:
+            if col.kind == "plain":
                 d.G[k] = X.reshape(1, 1, *X.shape)
-            else:
-                Cc = self.canonC(k)                                   # (ca, px, cb)
+            elif col.kind == "conv":
+                Fc = self.canonF(k)                                   # (ca, px, cb)
                 S, p, px = X.shape
-                flat = X.reshape(S * p, px) @ Cc.permute(1, 0, 2).reshape(px, col.ca * col.cb)   # library GEMM
+                flat = X.reshape(S * p, px) @ Fc.permute(1, 0, 2).reshape(px, col.ca * col.cb)
                 d.G[k] = flat.reshape(S, p, col.ca, col.cb).permute(2, 3, 0, 1).contiguous()
+            else:
+                Fc = self.canonF(k)                                   # (ca, u, dd, cb)
+                u, dd = col.inner
+                flat = X @ Fc.permute(2, 0, 3, 1).reshape(dd, col.ca * col.cb * u)
+                d.G[k] = flat.reshape(X.shape[0], col.ca, col.cb, u).permute(1, 2, 0, 3).contiguous()
         return d.G[k]
 
     def left(self, d, k):
@@ -414,6 +486,12 @@ class ChainEngine:
                 d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
         return d.R[k]
 
+    def refresh(self, d):
+        """Bring every cached environment up to date (the reference's recompute_all_stacks)."""
+        self.sync(d)
+        self.left(d, len(self.cols) - 1)
+        self.right(d, 0)
+
     def predict(self, d, k=None):
         """(S, C) prediction, cut at column k (default: the cheapest cut)."""
         self.sync(d)
@@ -441,47 +519,32 @@ class ChainEngine:
         S, C = d.S, L.shape[2]
         core = self.canonA(k)
         col = self.cols[k]
+        back = lambda t, node=node: self.from_canon(node, t)   # noqa: E731
         if kind == "A":
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
-            return LocalProblem(S, C, (col.rl, col.p, col.rr), core, lambda t, k=k: self.backA(k, t), terms=terms)
-        # conv node: J[s,c,a,x,b] = sum_patch M_ab[s,c,patch] X[s,patch,x],
-        # M_ab = L_a . (A . R_b); all three products are plain (batched) library GEMMs
-        Cc = self.canonC(k)
+            return LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
+        # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (plain batched library GEMMs)
+        #   conv filter    J[s,c,a,x,b]   = sum_patch M_ab[s,c,patch] X[s,patch,x]
+        #   operator node  J[s,c,a,u,d,b] = M_ab[s,c,u] X[s,d]   (one Khatri-Rao term when a = b = 1)
+        Fc = self.canonF(k)
         X = d.xs[k]
-        ca, cb, px = col.ca, col.cb, col.px
-        J = torch.empty((S, C, ca, px, cb), dtype=F64, device=X.device)
+        ca, cb = col.ca, col.cb
         A2 = core.reshape(col.rl * col.p, col.rr)
-        for b in range(cb):
+
+        def M(a, b):
             U = (R[b] @ A2.T).reshape(S, col.rl, col.p)
+            return torch.bmm(L[a], U)                      # (S, C, p)
+
+        if col.kind == "op" and ca == 1 and cb == 1:
+            u, dd = col.inner
+            ones = torch.ones((S, 1), dtype=F64, device=X.device)
+            return LocalProblem(S, C, (u, dd, 1), Fc.reshape(u, dd, 1), back, terms=[(M(0, 0).contiguous(), X, ones)])
+        J = torch.empty((S, C, ca) + col.inner + (cb,), dtype=F64, device=X.device)
+        for b in range(cb):
             for a in range(ca):
-                M = torch.bmm(L[a], U)                      # (S, C, p)
-                J[:, :, a, :, b] = torch.bmm(M, X)          # (S, C, px)
-        return LocalProblem(S, C, (ca, px, cb), Cc, lambda t, k=k: self.backC(k, t), J=J.reshape(S, C, ca * px * cb))
-
-    def to_canon(self, node, v):
-        k, kind = self.column_of(node)
-        col = self.cols[k]
-        if kind == "A":
-            self.canonA(k)
-            return ops.prep(v.permute(self.permA(k)).reshape(col.rl, col.p, col.rr))
-        self.canonC(k)
-        return ops.prep(v.permute(self.permC(k)).reshape(col.ca, col.px, col.cb))
-
-    # ------------------------------------------------------------------ Gram + solve
-    def gram_ws(self, lp, H, sym):
-        L, X, R = lp.terms[0]
-        key = (lp.S, lp.C, L.shape[2], X.shape[1], R.shape[1], int(sym))
-        ws = self._gram_ws.get(key)
-        if ws is None:
-            self._gram_ws.clear()
-        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
-        self._gram_ws[key] = ws
-        return ws
-
-    def dense_buffer(self, D, device):
-        buf = self._abuf.get(D)
-        if buf is None:
-            self._abuf.clear()
-            buf = torch.empty((D, D), dtype=F64, device=device)
-            self._abuf[D] = buf
-        return buf
+                if col.kind == "conv":
+                    J[:, :, a, :, b] = torch.bmm(M(a, b), X)                       # (S, C, px)
+                else:
+                    J[:, :, a, :, :, b] = M(a, b).unsqueeze(-1) * X.reshape(S, 1, 1, -1)
+        shape = (ca,) + col.inner + (cb,)
+        return LocalProblem(S, C, shape, Fc, back, J=J.reshape(S, C, -1))

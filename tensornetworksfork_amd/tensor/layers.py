@@ -239,3 +239,142 @@ class TensorConvolutionTrainLayer(TensorNetworkLayer):
         self.nodes = order
         self.input_nodes, self.main_nodes = xs, trains
         self.train_nodes = trains + convs
+
+
+def _seed_all(seed):
+    if seed is not None:
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(seed)
+
+
+class TensorTrainLinearLayer(TensorNetworkLayer):
+    def __init__(self, num_carriages, bond_dim, input_features, linear_dim, output_shape=tuple(), squeeze=True,
+                 constrict_bond=True, perturb=False, dtype=None, seed=None):
+        """Tensor train whose site i sees a learned linear map L_i (lin_i, p_i) of its input
+        (tensor/layers.py:308-343): A_i --lin_i-- L_i --p_i-- X_i.  Draw order: cores, maps, inputs;
+        train_nodes = [A1, L1, A2, L2, ...]."""
+        super().__init__()
+        self.num_carriages, self.bond_dim, self.input_features = num_carriages, bond_dim, input_features
+        self.output_shape = output_shape if isinstance(output_shape, tuple) else (output_shape,)
+        self.linear_dim = linear_dim
+        _seed_all(seed)
+        self.main_node_layer = MainNodeLayer(num_carriages, bond_dim, linear_dim, output_shape=output_shape,
+                                             down_label='lin{0}', constrict_bond=constrict_bond, perturb=perturb,
+                                             dtype=dtype)
+        self.horizontal_connect(self.main_node_layer.nodes)
+        self.linear_layer = NodeLayer(num_carriages, (linear_dim, input_features), labels=('lin{0}', 'p{0}'), dtype=dtype)
+        self.zip_connect(self.main_node_layer.nodes, self.linear_layer.nodes, label='lin{0}', priority=2)
+        self.input_node_layer = InputNodeLayer(num_carriages, input_features, label='p{0}', dtype=dtype)
+        self.zip_connect(self.linear_layer.nodes, self.input_node_layer.nodes, label='p{0}', priority=1)
+        if squeeze:
+            for n in self.main_node_layer.nodes:
+                n.squeeze(self.main_node_layer.labels)
+        train = [n for pair in zip(self.main_node_layer.nodes, self.linear_layer.nodes) for n in pair]
+        self.set_tensor_network(TensorNetwork(self.input_node_layer.nodes, main_nodes=self.main_node_layer.nodes,
+                                              train_nodes=train, output_labels=self.main_node_layer.labels))
+
+
+class OperatorNodeLayer(nn.Module):
+    def __init__(self, N, operator, bond_label='b{0}', up_label='u{0}', down_label='d{0}', ring=False, left=None,
+                 right=None, dtype=None):
+        """Fixed operator nodes O1..ON labelled [b_{i-1}, up_i, down_i, b_i] forming a matrix-product
+        operator (tensor/layers.py:368-406): `operator` per site (list) or shared, with optional
+        distinct first / last tensors."""
+        super().__init__()
+        self.nodes = []
+        for i in range(N):
+            if isinstance(operator, (list, tuple)):
+                t = operator[i]
+            elif not ring and i == 0 and left is not None:
+                t = left
+            elif not ring and i == N - 1 and right is not None:
+                t = right
+            else:
+                t = operator
+            lb = bond_label if ring and i == 0 else bond_label.format(i)
+            rb = bond_label if ring and i == N - 1 else bond_label.format(i + 1)
+            self.nodes.append(TensorNode(t, [lb, up_label.format(i + 1), down_label.format(i + 1), rb], l=lb, r=rb,
+                                         name=f"O{i + 1}", dtype=dtype))
+        self.labels = []
+
+
+def get_cum_sum_operator(n, num_carriages, input_features, dtype=None):
+    """Site n of the cumulative-sum operator (tensor/layers.py:408-423):
+    O[a, k, l, m] = [a <= k] [k == l] [m == k]  (m collapses to 0 on the last site, a to 0 on the first)."""
+    f = input_features
+    left = 1 if n == 0 else f
+    right = 1 if n == num_carriages - 1 else f
+    op = torch.zeros((left, f, f, right), dtype=dtype)
+    for k in range(f):
+        op[:min(left, k + 1), k, k, 0 if right == 1 else k] = 1
+    return op
+
+
+class CumSumLayer(TensorNetworkLayer):
+    def __init__(self, num_carriages, bond_dim, input_features, output_shape=tuple(), squeeze=True, constrict_bond=True,
+                 perturb=False, dtype=None, seed=None):
+        """Tensor train reading its inputs through the fixed cumulative-sum operator
+        (tensor/layers.py:425-477): A_i --p_i-- O_i --d_i-- X_i, O's chained on b.  The constructor
+        takes `seed` but, like the reference, does not seed the generator."""
+        super().__init__()
+        self.num_carriages, self.input_features = num_carriages, input_features
+        self.main_node_layer = MainNodeLayer(num_carriages, bond_dim, input_features, output_shape=output_shape,
+                                             down_label='p{0}', constrict_bond=constrict_bond, perturb=perturb,
+                                             dtype=dtype)
+        self.horizontal_connect(self.main_node_layer.nodes)
+        if num_carriages > 1:
+            ops_ = [get_cum_sum_operator(n, num_carriages, input_features, dtype=dtype)
+                    for n in (0, 1, num_carriages - 1)]
+            self.operator_layer = OperatorNodeLayer(num_carriages, operator=ops_[1], left=ops_[0], right=ops_[2],
+                                                    up_label='p{0}', down_label='d{0}', dtype=dtype)
+            self.input_node_layer = InputNodeLayer(num_carriages, input_features, label='d{0}', dtype=dtype)
+            self.horizontal_connect(self.operator_layer.nodes)
+            self.zip_connect(self.main_node_layer.nodes, self.operator_layer.nodes, label='p{0}', priority=2)
+            self.zip_connect(self.operator_layer.nodes, self.input_node_layer.nodes, label='d{0}', priority=1)
+            for n in self.operator_layer.nodes:
+                n.squeeze()
+        else:
+            self.input_node_layer = InputNodeLayer(num_carriages, input_features, label='p{0}', dtype=dtype)
+            self.zip_connect(self.input_node_layer.nodes, self.main_node_layer.nodes, label='p{0}', priority=1)
+        if squeeze:
+            for n in self.main_node_layer.nodes:
+                n.squeeze(self.main_node_layer.labels)
+        self.set_tensor_network(TensorNetwork(input_nodes=self.input_node_layer.nodes,
+                                              main_nodes=self.main_node_layer.nodes,
+                                              train_nodes=self.main_node_layer.nodes,
+                                              output_labels=self.main_node_layer.labels))
+
+
+class CPDLayer(TensorNetworkLayer):
+    def __init__(self, num_factors, rank, input_features, output_shape=tuple(), perturb=False, seed=None):
+        """Canonical polyadic model (tensor/layers.py:1549-1625): inputs X_i (s, p) are drawn first,
+        then factors A_1 (b, p, o) -- (p, o) when it is the only factor -- and A_i (b, p); every
+        X_i--A_i edge is labelled 'p' and the rank label 'b' is shared without edges.  `perturb`
+        starts factors 2..N as selectors of the last feature (the last one with 2 % noise)."""
+        from .network import CPDNetwork
+        self.num_factors, self.rank, self.input_features = num_factors, rank, input_features
+        self.output_shape = output_shape if isinstance(output_shape, tuple) else (output_shape,)
+        _seed_all(seed)
+        self.x_nodes = [TensorNode((1, input_features), ['s', 'p'], name=f"X{i}") for i in range(1, num_factors + 1)]
+        nodes = []
+        for i in range(1, num_factors + 1):
+            if i == 1:
+                out_dim = self.output_shape[0] if self.output_shape else 1
+                if num_factors == 1:
+                    nodes.append(TensorNode((input_features, out_dim), ['p', 'o'], name="A1"))
+                else:
+                    nodes.append(TensorNode((rank, input_features, out_dim), ['b', 'p', 'o'], name="A1"))
+                continue
+            spec = (rank, input_features)
+            if perturb:
+                last = torch.ones(rank, 1)
+                if i == num_factors:
+                    last = last + 0.02 * torch.randn(rank, 1)
+                spec = torch.cat((torch.zeros(rank, input_features - 1), last), dim=1)
+            nodes.append(TensorNode(spec, ['b', 'p'], name=f"A{i}"))
+        for x, a in zip(self.x_nodes, nodes):
+            x.connect(a, 'p')
+        super().__init__(CPDNetwork(self.x_nodes, nodes, output_labels=('s', 'o'), sample_dim='s'))
+        self.nodes = nodes
+        self.labels = ['s', 'o']

@@ -35,7 +35,10 @@ class TensorNetwork:
         self.nodes, self.node_indices = self._discover_nodes()
         self._current = None
         self._shard = None
-        self._engine = ChainEngine(self)
+        self._engine = self._make_engine()
+
+    def _make_engine(self):
+        return ChainEngine(self)
 
     def distribute(self, shard="auto"):
         """Shard the training samples of the sweep methods over the ranks of a
@@ -88,9 +91,9 @@ class TensorNetwork:
 
     def _shape_output(self, y):
         """(S, C) -> TensorNode labelled like the reference's forward output."""
-        col = self._engine.cols[0]
-        sizes = [col.A.dim_size(lab) for lab in col.out_labels]
-        node = TensorNode(y.reshape([y.shape[0]] + sizes), [self.sample_dim] + list(col.out_labels), name='O')
+        eng = self._engine
+        labels = eng.out_labels()
+        node = TensorNode(y.reshape([y.shape[0]] + eng.out_sizes()), [self.sample_dim] + labels, name='O')
         if self.output_labels is not None:
             node.permute_first(*self.output_labels)
         return node
@@ -101,13 +104,8 @@ class TensorNetwork:
         self.right_stacks = None
 
     def recompute_all_stacks(self, exclude_nodes=set()):
-        d = self._current
-        if d is None:
-            return
-        eng = self._engine
-        eng.sync(d)
-        eng.left(d, len(eng.cols) - 1)
-        eng.right(d, 0)
+        if self._current is not None:
+            self._engine.refresh(self._current)
 
     def left_update_stacks(self, node):
         """Environments are refreshed lazily from node identities; nothing to do eagerly."""
@@ -228,9 +226,8 @@ class TensorNetwork:
         d, lp = self._local(node)
         sdim = self.sample_dim
         sizes, perm = self._engine.layout(node)
-        col0 = self._engine.cols[0]
-        out0 = list(col0.out_labels)
-        J = lp.rows(0, d.S).reshape([d.S] + [col0.A.dim_size(lab) for lab in out0] + list(sizes))
+        out0 = self._engine.out_labels()
+        J = lp.rows(0, d.S).reshape([d.S] + self._engine.out_sizes() + list(sizes))
         no = 1 + len(out0)
         inv = [perm.index(a) for a in range(len(perm))]
         J = J.permute(list(range(no)) + [no + a for a in inv])
@@ -290,7 +287,7 @@ class TensorNetwork:
         mean-of-batch-means loss (float, or None if not requested)."""
         lp = self._engine.local(d, node)
         core = lp.core
-        y_pred = lp.jv(core)                         # the output is linear in every single node
+        y_pred = self._engine.output_at(d, node, lp)  # the output is linear in every single node
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
         total = self._batch_mean_loss(d, loss, batch_size) if want_loss else None
@@ -352,7 +349,7 @@ class TensorNetwork:
         for b0 in range(0, d.S, batch_size):
             lo, hi = b0, min(d.S, b0 + batch_size)
             sub = lp.slice(lo, hi)
-            y_pred = sub.jv(self._engine.to_canon(node, node.tensor))
+            y_pred = self._engine.output_at(d, node, sub, self._engine.to_canon(node, node.tensor), rows=(lo, hi))
             loss, grad, _ = loss_fn.forward(self._shape_output(y_pred).tensor, y[lo:hi])
             bv = sub.rhs(ops.prep(grad.reshape(hi - lo, lp.C)))
             b_out = bv if b_out is None else b_out + bv
@@ -507,7 +504,7 @@ class TensorNetwork:
     def _krylov_setup(self, d, node, y, loss_fn, batch_size, want_loss):
         """RHS phase shared by lanczos_swipe / scipy_swipe (tensor/network.py:746-767)."""
         lp = self._engine.local(d, node)
-        y_pred = lp.jv(lp.core)
+        y_pred = self._engine.output_at(d, node, lp)
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
         b = lp.rhs(g)
@@ -551,7 +548,7 @@ class TensorNetwork:
                 if loss_callback is not None:
                     loss_callback(lossv)
                 x0n = torch.randn(tuple(node.tensor.shape), dtype=node.tensor.dtype)
-                x0 = self._engine.to_canon(node, x0n.to(device))
+                x0 = self._engine.to_canon(node, x0n.to(device)).reshape(lp.shape)
                 if d.sharded:
                     self._shard.broadcast_(x0)
                 step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol)
@@ -594,3 +591,77 @@ class TensorNetwork:
 
     def disconnect(self, nodes):
         raise NotImplementedError("disconnect() is not part of the core-update path of this build")
+
+
+class CPDNetwork(TensorNetwork):
+    """Canonical polyadic model: one factor node per input, all sharing an unconnected rank
+    label (tensor/network.py:935-986).  Per-factor tables replace the left/right environments."""
+
+    def _make_engine(self):
+        from .composite import CPDEngine
+        return CPDEngine(self)
+
+    def node_orthonormalize_left(self, node):
+        """Factors carry no bonds; the gauge moves of the train do not apply."""
+
+    def node_orthonormalize_right(self, node):
+        """See node_orthonormalize_left."""
+
+
+class SumOfNetworks(TensorNetwork):
+    """Sum of the outputs of several networks over one shared input (tensor/network.py:988-1060).
+    Nodes are renamed '<name>_n<i>'; train_operators=False trains the main nodes only.
+    `only_bias_first` / `train_linear` of older call sites are accepted and ignored."""
+
+    def __init__(self, networks, output_labels=('s',), sample_dim='s', train_operators=True, only_bias_first=None,
+                 train_linear=None):
+        input_nodes, main_nodes, train_nodes = [], [], []
+        for i, net in enumerate(networks, 1):
+            for n in list(net.input_nodes) + list(net.main_nodes):
+                n.name = f"{n.name}_n{i}"
+            input_nodes.extend(net.input_nodes)
+            main_nodes.extend(net.main_nodes)
+            train_nodes.extend(net.train_nodes if train_operators else net.main_nodes)
+        self.networks = networks
+        super().__init__(input_nodes, main_nodes, train_nodes, output_labels=output_labels, sample_dim=sample_dim)
+
+    def _make_engine(self):
+        from .composite import SumEngine
+        return SumEngine(self, self.networks)
+
+    def distribute(self, shard="auto"):
+        super().distribute(shard)
+        for net in self.networks:
+            net._shard = self._shard
+        return self
+
+    def set_input(self, x):
+        self._require_chain()
+        d = self._data_for(x)
+        changed = d is not self._current
+        self._current = d
+        return changed
+
+    def orthonormalize_left(self):
+        for net in self.networks:
+            net.orthonormalize_left()
+
+    def orthonormalize_right(self):
+        for net in self.networks:
+            net.orthonormalize_right()
+
+    def node_orthonormalize_left(self, node):
+        for net in self.networks:
+            if node in net.main_nodes:
+                net.node_orthonormalize_left(node)
+
+    def node_orthonormalize_right(self, node):
+        for net in self.networks:
+            if node in net.main_nodes:
+                net.node_orthonormalize_right(node)
+
+    def left_update_stacks(self, node):
+        raise NotImplementedError("left_update_stacks not implemented for SumOfNetworks")
+
+    def right_update_stacks(self, node):
+        raise NotImplementedError("right_update_stacks not implemented for SumOfNetworks")

@@ -45,3 +45,11 @@ def test_krylov_sweeps_host_logic(name, api):
 @pytest.mark.parametrize("name", G.names("tnml_fit_") + G.names("ttreg_fit_"))
 def test_estimators_host_logic(name, api):
     (api.test_tnml_fit_golden if name.startswith("tnml_") else api.test_ttreg_fit_golden)(name)
+
+
+@pytest.mark.parametrize("name", G.names("net_"))
+def test_other_topologies_host_logic(name, cpu_kernels):
+    from tests import test_nets_gpu as nets
+    nets.check_local_problems(name, "cpu")
+    nets.check_cholesky_sweep(name, "cpu")
+    nets.check_lanczos_sweep(name, "cpu")
