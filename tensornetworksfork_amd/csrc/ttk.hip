@@ -748,13 +748,13 @@ __global__ __launch_bounds__(256) void axpy_kernel(const double* __restrict__ a,
 // row nb holds the right-hand side in its first row and zeros below.  Because
 // [A b; b^T .] = [L 0; y^T .][L^T y; 0 .] the forward substitution y = L^-1 b falls out of
 // the panel solves of that extra row.  Per 64-column panel j:
-//   chol_diag_kernel  : L_jj = chol(A_jj) and its inverse, inside one workgroup's LDS;
-//   chol_panel_kernel : L_ij = A_ij * inv(L_jj)^T for every block row i > j      (MFMA);
+//   chol_panel_kernel : L_jj = chol(A_jj) and L_ij = A_ij L_jj^-T for every block row i > j, in
+//                       one launch (the diagonal block is factorised by every workgroup);
 //   chol_syrk_kernel  : A_ik -= L_i,panel * L_k,panel^T on the lower trailing blocks (MFMA).
 // Panels are applied to the trailing matrix two at a time (K = 128) so that the trailing
-// matrix, which is what bounds this factorisation (HBM read+write per panel), is swept
-// half as often; the block column in between gets a narrow K = 64 update.
-// The backward substitution x = L^-T y walks the block rows upward, one launch per block.
+// matrix is swept half as often; the block column in between gets a narrow K = 64 update
+// inside the panel kernel.  The backward substitution x = L^-T y walks the block rows upward,
+// four per launch, with the inverses of the diagonal blocks from chol_inv_kernel.
 // ---------------------------------------------------------------------------------------
 #define CHB 64
 
@@ -771,129 +771,243 @@ __device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
   sq = s;
 }
 
-// Panel j in one launch.  Every workgroup factorises the 64x64 diagonal block A_jj in
-// registers (thread (r,q) owns row r, columns c = q mod 4; one barrier per column), then
-// workgroup 0 stores L_jj and workgroup b >= 1 solves X L_jj^T = A_ij for block row
-// i = j + b by a right-looking substitution along its rows (4 lanes per row, no barrier).
-// Recomputing the small factorisation everywhere removes a launch and a global round trip
-// from the critical path.  With `fuse` set the pending update of block column j by the
-// previous panel (A_ij -= L_i,j-1 L_j,j-1^T, K = 64, MFMA) is applied on the fly first, so
-// that panels can be applied to the rest of the trailing matrix two at a time.
+// Uniform broadcast of one lane's double through two scalar lane reads (no LDS round trip).
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Panel j in one launch, blocked by 16 columns.  The 64 x 64 diagonal block T (every workgroup
+// factorises its own copy: no launch, no global round trip between factor and solve) and the
+// workgroup's own block row B (block row i = j + blockIdx.x; workgroup 0 only stores the
+// factor) sit in LDS.  Work items per 16-column sub-panel kb (P = T[:, kb], X = B[:, kb]):
+//   F(kb)   wave 0 : right-looking factorisation of the sub-panel, one matrix row per lane with
+//                    its 16 entries in registers.  The column loop carries only the reciprocal
+//                    pivot (A[r][cc] -= u_r u_cc / d, pivot column broadcast by scalar lane
+//                    reads); the 1/sqrt(d) scaling of the 16 columns follows the loop.
+//   S(kb)   wave 1 : the same column sweep on the rows of B (X L^T = B), coefficients read from
+//                    T as LDS broadcasts.
+//   TU(kb)         : T[:, right] -= P P^T  (MFMA, K = 16);  BU(kb): B[:, right] -= X P^T.
+// Only the tile column that the next sub-panel needs (TUcrit, BUcrit) sits between two
+// factorisation phases; S(kb-1) and the remaining tiles run beside F(kb):
+//   phase A_k : wave 0 F(k) | wave 1 S(k-1) | waves 2,3 TUrest(k-1), BUrest(k-2)
+//   phase B_k : all waves   TUcrit(k), BUcrit(k-1)
+// With `fuse` set the pending update of block column j by the previous panel (K = 64, MFMA) is
+// applied while the blocks are loaded, so that panels can be applied to the rest of the
+// trailing matrix two at a time.
+typedef double (*chol_lds_t)[CHB + 1];
+
+#ifdef TTK_DEBUG_HOOKS
+__device__ long long g_dbg[64];
+#define DBG(k) if (blockIdx.x == 1 && tid == 0 && (j == 40 || j == 41)) g_dbg[(j - 40) * 16 + (k)] = wall_clock64();
+#else
+#define DBG(k)
+#endif
+
+// dst tile (tr, tc) -= rows tr of src-panel (columns pc..pc+15 of A) times rows tc of T's panel
+__device__ __forceinline__ void chol_tile_update(chol_lds_t dst, chol_lds_t lhs, chol_lds_t T, int tr, int tc, int pc,
+                                                 int li, int kq) {
+  d4 acc;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = dst[tr * 16 + kq + 4 * t][tc * 16 + li];
+#pragma unroll
+  for (int k0 = 0; k0 < 16; k0 += 4) acc = MFMA_F64(-lhs[tr * 16 + li][pc + k0 + kq], T[tc * 16 + li][pc + k0 + kq], acc);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[tr * 16 + kq + 4 * t][tc * 16 + li] = acc[t];
+}
+
+__device__ __forceinline__ double rcp_f64(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(y, fma(-d, y, 1.0), y);
+  y = fma(y, fma(-d, y, 1.0), y);
+  return y;
+}
+
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ aug, int ld, int j, int fuse,
-                                                          int* __restrict__ info) {
+                                                            int* __restrict__ info) {
   __shared__ double T[CHB][CHB + 1];
-  __shared__ double B0[CHB][CHB + 1];
-  __shared__ double B1[CHB][CHB + 1];
-  __shared__ double colbuf[2][CHB];
-  __shared__ double rdiag[CHB];
+  __shared__ double B[CHB][CHB + 1];
+  __shared__ double S0[CHB][CHB + 1];
+  __shared__ double S1[CHB][CHB + 1];
+  __shared__ double rsd[CHB];
+  __shared__ double piv[16];
   const int tid = threadIdx.x;
-  const int r = tid >> 2, q = tid & 3;
-  const int i = j + blockIdx.x;   // block row of this workgroup (== j: stores the factor)
-  const double* diag = aug + ((int64_t)j * CHB) * ld + (int64_t)j * CHB;
-  double* blk = aug + ((int64_t)i * CHB) * ld + (int64_t)j * CHB;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int i = j + blockIdx.x;
+  const bool own = blockIdx.x != 0;
+  DBG(0)
+  double* diag = aug + ((int64_t)j * CHB) * ld + (int64_t)j * CHB;
+  double* blk = aug + ((int64_t)i * CHB) * ld + (int64_t)j * CHB;   // == diag for workgroup 0
   if (fuse) {
-    // B0[kk][r] = L_j,j-1[r][kk],  B1[kk][r] = L_i,j-1[r][kk]
-    const double* Pd = aug + ((int64_t)j * CHB) * ld + (int64_t)(j - 1) * CHB;
-    const double* Pi = aug + ((int64_t)i * CHB) * ld + (int64_t)(j - 1) * CHB;
-    for (int idx = tid; idx < CHB * CHB; idx += 256) {
-      const int rr_ = idx >> 6, kk = idx & 63;
-      B0[kk][rr_] = Pd[(int64_t)rr_ * ld + kk];
-      B1[kk][rr_] = Pi[(int64_t)rr_ * ld + kk];
+    // S0[kk][r] = L_j,j-1[r][kk],  S1[kk][r] = L_i,j-1[r][kk]; all loads unconditional and in flight together
+    const double* Pd = diag - CHB;
+    const double* Pi = blk - CHB;
+    double pd[16], pi[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      pd[e] = Pd[(int64_t)(idx >> 6) * ld + (idx & 63)];
+      pi[e] = Pi[(int64_t)(idx >> 6) * ld + (idx & 63)];
     }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     d4 ud[4], ui[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) ud[t] = ui[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < CHB; k0 += 4) {
-      const double ad = B0[k0 + kq][wave * 16 + li];
-      const double ai = B1[k0 + kq][wave * 16 + li];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double b = B0[k0 + kq][t * 16 + li];
-        ud[t] = MFMA_F64(ad, b, ud[t]);
-        ui[t] = MFMA_F64(ai, b, ui[t]);
-      }
-    }
-    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        B0[wave * 16 + kq + 4 * u][t * 16 + li] = ud[t][u];
-        B1[wave * 16 + kq + 4 * u][t * 16 + li] = ui[t][u];
+        const int row = wave * 16 + kq + 4 * u, col = t * 16 + li;
+        ud[t][u] = diag[(int64_t)row * ld + col];
+        ui[t][u] = blk[(int64_t)row * ld + col];
       }
-    __syncthreads();
-  }
-  double a[16];
 #pragma unroll
-  for (int sl = 0; sl < 16; ++sl) {
-    const int c = 4 * sl + q;
-    double v = (c <= r) ? diag[(int64_t)r * ld + c] : 0.0;
-    if (fuse && c <= r) v -= B0[r][c];
-    a[sl] = v;
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      S0[idx & 63][idx >> 6] = pd[e];
+      S1[idx & 63][idx >> 6] = pi[e];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t * 16 + li > wave * 16 + kq + 4 * u) ud[t][u] = 0.0;   // only the lower triangle of A_jj is kept
+    __syncthreads();
+#pragma unroll 4
+    for (int k0 = 0; k0 < CHB; k0 += 4) {
+      const double ad = -S0[k0 + kq][wave * 16 + li];
+      const double ai = -S1[k0 + kq][wave * 16 + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = S0[k0 + kq][t * 16 + li];
+        ud[t] = MFMA_F64(ad, b, ud[t]);
+        ui[t] = MFMA_F64(ai, b, ui[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        T[wave * 16 + kq + 4 * u][t * 16 + li] = ud[t][u];
+        B[wave * 16 + kq + 4 * u][t * 16 + li] = ui[t][u];
+      }
+  } else {
+    double vd[16], vb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      vd[e] = diag[(int64_t)(idx >> 6) * ld + (idx & 63)];
+      vb[e] = blk[(int64_t)(idx >> 6) * ld + (idx & 63)];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      const int rr_ = idx >> 6, cc = idx & 63;
+      T[rr_][cc] = (cc <= rr_) ? vd[e] : 0.0;
+      B[rr_][cc] = vb[e];
+    }
   }
+  __syncthreads();
+  DBG(1)
   bool bad = false;
   int badcol = 0;
+#pragma unroll 1
+  for (int ph = 0; ph <= 4; ++ph) {
+    const int c0 = ph * 16;
+    // ---------------- phase A
+    if (wave == 0) {
+      if (ph < 4) {   // F(ph)
+        double a[16];
 #pragma unroll
-  for (int c = 0; c < CHB; ++c) {
-    const int sl = c >> 2, qo = c & 3;
-    if (q == qo) colbuf[c & 1][r] = a[sl];
+        for (int c = 0; c < 16; ++c) a[c] = T[lane][c0 + c];
+        // The pivots are parked in LDS for the vectorised 1/sqrt after the loop.  A non-positive or
+        // NaN pivot is not repaired here: what follows it is garbage, `info` reports it and the
+        // caller discards the result.
+        double d = readlane_f64(a[0], c0);
+        double rc = rcp_f64(d);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (lane == 0) piv[c] = d;
+          const double t = -a[c] * rc;
+          if (c + 1 < 16) {   // next pivot first: its reciprocal chain runs under the other updates
+            a[c + 1] = fma(t, readlane_f64(a[c], c0 + c + 1), a[c + 1]);
+            d = readlane_f64(a[c + 1], c0 + c + 1);
+            rc = rcp_f64(d);
+          }
+#pragma unroll
+          for (int cc = c + 2; cc < 16; ++cc) a[cc] = fma(t, readlane_f64(a[c], c0 + cc), a[cc]);
+        }
+        const double dv = piv[lane & 15];
+        double rsv, sqv;
+        rsqrt_sqrt(dv, rsv, sqv);
+        const unsigned long long badmask = __ballot(!(dv > 0.0)) & 0xffffull;
+        if (badmask && !bad) {
+          bad = true;
+          badcol = c0 + __builtin_ctzll(badmask);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] *= readlane_f64(rsv, c);
+        if (lane < 16) rsd[c0 + lane] = rsv;
+        if (lane >= c0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) T[lane][c0 + c] = a[c];
+        }
+      }
+    } else if (wave == 1) {
+      if (own && ph >= 1) {   // S(ph-1)
+        const int s0 = c0 - 16;
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = B[lane][s0 + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          a[c] *= rsd[s0 + c];
+#pragma unroll
+          for (int cc = c + 1; cc < 16; ++cc) a[cc] = fma(-a[c], T[s0 + cc][s0 + c], a[cc]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) B[lane][s0 + c] = a[c];
+      }
+    } else {
+      int n = wave - 2;   // tiles dealt alternately to waves 2 and 3
+      if (ph >= 1) {      // TUrest(ph-1): lower tiles with column >= ph+1
+        for (int tj = ph + 1; tj < 4; ++tj)
+          for (int ti = tj; ti < 4; ++ti, ++n)
+            if (!(n & 1)) chol_tile_update(T, T, T, ti, tj, c0 - 16, li, kq);
+      }
+      if (own && ph >= 2) {   // BUrest(ph-2): tile columns >= ph
+        for (int tc = ph; tc < 4; ++tc)
+          for (int tr = 0; tr < 4; ++tr, ++n)
+            if (!(n & 1)) chol_tile_update(B, B, T, tr, tc, c0 - 32, li, kq);
+      }
+    }
     __syncthreads();
-    double d = colbuf[c & 1][c];
-    if (!(d > 0.0)) {
-      if (!bad) badcol = c;
-      bad = true;
-      d = 1.0;
+    DBG(2 + 2 * ph)
+    if (ph == 4) break;
+    // ---------------- phase B: TUcrit(ph) = tiles (ti, ph+1); BUcrit(ph-1) = tiles (tr, ph)
+    {
+      int n = wave;
+      if (ph < 3)
+        for (int ti = ph + 1; ti < 4; ++ti, ++n)
+          if (!(n & 3)) chol_tile_update(T, T, T, ti, ph + 1, c0, li, kq);
+      if (own && ph >= 1)
+        for (int tr = 0; tr < 4; ++tr, ++n)
+          if (!(n & 3)) chol_tile_update(B, B, T, tr, ph, c0 - 16, li, kq);
     }
-    double rs, sq;
-    rsqrt_sqrt(d, rs, sq);
-    const double my_l = colbuf[c & 1][r] * rs;
-#pragma unroll
-    for (int s2 = sl; s2 < 16; ++s2) {
-      const int cc = 4 * s2 + q;
-      const double lc = colbuf[c & 1][cc] * rs;
-      if (cc > c) a[s2] -= my_l * lc;
+    __syncthreads();
+    DBG(3 + 2 * ph)
+  }
+  if (!own) {
+    if (wave == 0 && bad && lane == 0 && *info == 0) *info = j * CHB + badcol + 1;
+    for (int idx = tid; idx < CHB * CHB; idx += 256) {
+      const int rr_ = idx >> 6, cc = idx & 63;
+      if (cc <= rr_) diag[(int64_t)rr_ * ld + cc] = T[rr_][cc];
     }
-    if (q == qo) {
-      a[sl] = (r == c) ? sq : my_l;
-      if (r == c) rdiag[c] = rs;
+  } else {
+    for (int idx = tid; idx < CHB * CHB; idx += 256) {
+      const int rr_ = idx >> 6, cc = idx & 63;
+      blk[(int64_t)rr_ * ld + cc] = B[rr_][cc];
     }
   }
-#pragma unroll
-  for (int sl = 0; sl < 16; ++sl) T[r][4 * sl + q] = a[sl];
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (bad && tid == 0 && *info == 0) *info = j * CHB + badcol + 1;
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) {
-      const int c = 4 * sl + q;
-      if (c <= r) blk[(int64_t)r * ld + c] = a[sl];
-    }
-    return;
-  }
-#pragma unroll
-  for (int sl = 0; sl < 16; ++sl) {
-    double v = blk[(int64_t)r * ld + 4 * sl + q];
-    if (fuse) v -= B1[r][4 * sl + q];
-    a[sl] = v;
-  }
-  const int lane = tid & 63;
-#pragma unroll
-  for (int c = 0; c < CHB; ++c) {
-    const int sl = c >> 2, qo = c & 3;
-    const double mine = a[sl] * rdiag[c];
-    const double x = __shfl(mine, (lane & ~3) | qo, 64);
-    if (q == qo) a[sl] = x;
-#pragma unroll
-    for (int s2 = sl; s2 < 16; ++s2) {
-      const int cc = 4 * s2 + q;
-      if (cc > c) a[s2] -= x * T[cc][c];
-    }
-  }
-#pragma unroll
-  for (int sl = 0; sl < 16; ++sl) blk[(int64_t)r * ld + 4 * sl + q] = a[sl];
+  DBG(11)
 }
 
 // invL[j] = inverse of the lower-triangular diagonal block L_jj, all blocks in one launch
@@ -971,33 +1085,40 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
   double pa[8], pb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    pa[e] = -Ap[e];
+    pa[e] = Ap[e];
     pb[e] = Bp[e];
   }
+  // The accumulators start at zero; the C tile is fetched in four quarters (one 16-row group of
+  // every wave per k-chunk) underneath the products of the first four chunks and added in, so
+  // that its latency is not paid in front of the loop.
   d4 acc[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = min(r0 + wr * 64 + u * 16 + kq + 4 * t, nrows - 1);
+    for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+  const int ccol0 = c0 + wc * 64 + li;
+  int q = 0;
+  for (int kc = 0; kc < K; kc += SYK, ++q) {
+    double ct[4][4];
+    if (q < 4) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int col = min(c0 + wc * 64 + v * 16 + li, ncols - 1);
-        acc[u][v][t] = aug[(int64_t)row * ld + col];
+      for (int t = 0; t < 4; ++t) {
+        const double* crow = aug + (int64_t)min(r0 + wr * 64 + q * 16 + kq + 4 * t, nrows - 1) * ld;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ct[v][t] = crow[min(ccol0 + v * 16, ncols - 1)];
       }
     }
-  for (int kc = 0; kc < K; kc += SYK) {
     if (kc) __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      As[sk + e][srow] = pa[e];
+      As[sk + e][srow] = -pa[e];   // negated here, not at the load: nothing may wait on the prefetch early
       Bs[sk + e][srow] = pb[e];
     }
     __syncthreads();
     if (kc + SYK < K) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        pa[e] = -Ap[kc + SYK + e];
+        pa[e] = Ap[kc + SYK + e];
         pb[e] = Bp[kc + SYK + e];
       }
     }
@@ -1014,6 +1135,28 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[u][v] = MFMA_F64(af[u], bf[v], acc[u][v]);
     }
+    if (q < 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u == q) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[u][v][t] += ct[v][t];
+        }
+    }
+  }
+  for (; q < 4; ++q) {   // K < 64: quarters the loop did not reach
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u == q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double* crow = aug + (int64_t)min(r0 + wr * 64 + q * 16 + kq + 4 * t, nrows - 1) * ld;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][v][t] += crow[min(ccol0 + v * 16, ncols - 1)];
+        }
+      }
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -1030,38 +1173,88 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
     }
 }
 
-// One step of x = L^-T y: x_j = invL_jj^T y_j (every workgroup recomputes it, workgroup 0
-// stores it), then y_k -= L_jk^T x_j for block k = blockIdx.x < j.  y is the first row of the
-// extra block row of `aug`.  256 threads: 64 columns x 4 row groups, partial sums through LDS.
-__global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug, int ld, int nb, int j,
+// Backward substitution x = L^-T y, BKG block rows per launch (jlo .. jhi, walked downward).
+// Every workgroup first solves the small triangular system of the group itself
+//   x_j = invL_jj^T (y_j - sum_{j < m <= jhi} L_mj^T x_m)
+// (recomputed everywhere: no second launch, workgroup 0 stores x), then workgroup k < jlo
+// removes the group from its own block: y_k -= sum_m L_mk^T x_m.  y is the first row of the
+// extra block row of `aug`.  256 threads = 64 columns x 4 row groups of 16 rows; everything a
+// thread multiplies is fetched into registers up front (unconditional, coalesced loads), so the
+// serial part runs on registers and LDS reductions only.
+#define BKG 4
+__global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug, int ld, int nb, int jlo, int jhi,
                                                         const double* __restrict__ invL_all, double* __restrict__ x,
                                                         int n) {
-  __shared__ double part[4][CHB];
-  __shared__ double xs[CHB];
+  __shared__ double part[BKG][4][CHB];
+  __shared__ double xs[BKG][CHB];
+  __shared__ double ys[BKG][CHB];
   double* y = aug + ((int64_t)nb * CHB) * ld;
-  const double* invL = invL_all + (int64_t)j * CHB * CHB;
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  double acc = 0.0;
-#pragma unroll 4
-  for (int r = g * 16; r < g * 16 + 16; ++r)
-    if (r >= c) acc += invL[r * CHB + c] * y[j * CHB + r];
-  part[g][c] = acc;
-  __syncthreads();
-  if (g == 0) {
-    const double v = part[0][c] + part[1][c] + part[2][c] + part[3][c];
-    xs[c] = v;
-    if (blockIdx.x == 0 && j * CHB + c < n) x[j * CHB + c] = v;
-  }
-  __syncthreads();
+  const int ng = jhi - jlo + 1;
   const int k = blockIdx.x;
-  if (k < j) {
-    const double* Ljk = aug + ((int64_t)j * CHB) * ld + (int64_t)k * CHB;
+  const bool tail = k < jlo;
+  double iv[BKG][16], lg[BKG][BKG - 1][16], gl[BKG][16];
+#pragma unroll
+  for (int m = 0; m < BKG; ++m) {
+    const int mm = m < ng ? m : ng - 1;   // clamped, never used when m >= ng
+    const double* invL = invL_all + (int64_t)(jlo + mm) * CHB * CHB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) iv[m][e] = invL[(g * 16 + e) * CHB + c];
+#pragma unroll
+    for (int t = 0; t < BKG - 1; ++t) {   // rows of block jlo+m against columns of block jlo+t (t < m)
+      const int tt = t < mm ? t : 0;
+      const double* Lmt = aug + ((int64_t)(jlo + mm) * CHB + g * 16) * ld + (int64_t)(jlo + tt) * CHB + c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lg[m][t][e] = Lmt[(int64_t)e * ld];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < BKG; ++m) {
+    const int mm = m < ng ? m : ng - 1;
+    const double* Lmk = aug + ((int64_t)(jlo + mm) * CHB + g * 16) * ld + (int64_t)(tail ? k : 0) * CHB + c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gl[m][e] = Lmk[(int64_t)e * ld];
+  }
+  if (g < ng) ys[g][c] = y[(jlo + g) * CHB + c];
+  __syncthreads();
+#pragma unroll
+  for (int m = BKG - 1; m >= 0; --m) {
+    if (m < ng) {   // uniform
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc += (g * 16 + e >= c ? iv[m][e] : 0.0) * ys[m][g * 16 + e];
+      part[0][g][c] = acc;
+      __syncthreads();
+      if (g == 0) {
+        const double v = part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c];
+        xs[m][c] = v;
+        if (k == 0 && (jlo + m) * CHB + c < n) x[(jlo + m) * CHB + c] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < BKG - 1; ++t)
+        if (t < m) {
+          double s = 0.0;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += lg[m][t][e] * xs[m][g * 16 + e];
+          part[t][g][c] = s;
+        }
+      __syncthreads();
+      if (g < m) ys[g][c] -= part[g][0][c] + part[g][1][c] + part[g][2][c] + part[g][3][c];
+      __syncthreads();
+    }
+  }
+  if (tail) {
     double s = 0.0;
-#pragma unroll 4
-    for (int r = g * 16; r < g * 16 + 16; ++r) s += Ljk[(int64_t)r * ld + c] * xs[r];
-    part[g][c] = s;
+#pragma unroll
+    for (int m = 0; m < BKG; ++m)
+      if (m < ng) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += gl[m][e] * xs[m][g * 16 + e];
+      }
+    part[0][g][c] = s;
     __syncthreads();
-    if (g == 0) y[k * CHB + c] -= part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    if (g == 0) y[k * CHB + c] -= part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c];
   }
 }
 
@@ -1385,6 +1578,14 @@ static void chol_syrk_launch(hipStream_t st, double* aug, int ld, int pc0, int K
   hipLaunchKernelGGL(chol_syrk_kernel, dim3(grid), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, nst_rows);
 }
 
+#ifdef TTK_DEBUG_HOOKS
+int ttk_debug_syrk(double* aug, int ld, int pc0, int K, int o0, int nrows, int ncols, void* stream) {
+  chol_syrk_launch((hipStream_t)stream, aug, ld, pc0, K, o0, nrows, ncols);
+  return 0;
+}
+int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
+#endif
+
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
   if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1401,14 +1602,19 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   for (int j = 0; j < nb; ++j) {
     // odd panels first absorb the previous panel's update of their own block column
     hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info);
-    // panels j-1 and j together (K = 128) onto everything right of column j
+    // panels j-1 and j together (K = 128) onto everything right of column j.  (Four panels per
+    // trailing update, K = 256, with a narrow K = 128 update in between, was measured slower:
+    // the narrow update costs a full tile latency.)
     if ((j & 1) && j + 1 < nb) chol_syrk_launch(st, aug, ld, (j - 1) * CHB, 2 * CHB, (j + 1) * CHB, nrows, ncols);
   }
   hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, invL);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
-  for (int j = nb - 1; j >= 0; --j)
-    hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(j > 0 ? j : 1)), dim3(256), 0, st, aug, ld, nb, j, invL, x, n);
+  for (int jhi = nb - 1; jhi >= 0; jhi -= BKG) {
+    const int jlo = jhi - BKG + 1 > 0 ? jhi - BKG + 1 : 0;
+    hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(jlo > 0 ? jlo : 1)), dim3(256), 0, st, aug, ld, nb, jlo, jhi, invL,
+                       x, n);
+  }
   return ttk_launch_status();
 }
 
