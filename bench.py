@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=54000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,8 +188,12 @@ def main():
     ups = args.steps / elapsed
     S_local = S_train // world + (1 if S_train % world else 0)
     MP = BOND * (BOND + 1) // 2
-    NX = (DEGREE + 1) * (DEGREE + 2) // 2
-    gram_flops = 2.0 * S_local * MP * NX * MP           # distinct entries of the symmetric Gram x samples
+    # distinct entries of the Gram x samples: (l<=m) x classes of (p,q) x (r<=t); the polynomial basis
+    # X_p = x^p has X_p X_q = x^(p+q), i.e. 2*degree+1 classes instead of (degree+1)(degree+2)/2 pairs
+    from tensornetworksfork_amd.tensor.engine import pair_classes
+    rep = pair_classes(F[N_SITES // 2][:4096].contiguous())
+    NX = (DEGREE + 1) * (DEGREE + 2) // 2 if rep is None else len(set(rep))
+    gram_flops = 2.0 * S_local * MP * NX * MP
     D = BOND * (DEGREE + 1) * BOND
     avg_ms = float(np.mean(gram_ms)) if gram_ms else float("nan")
     achieved = gram_flops / (avg_ms * 1e-3) * 1e-12
@@ -214,7 +218,7 @@ def main():
         "roofline": {"kernel": "gram_kernel<true>", "bound": "mfma", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "launches": len(gram_ms), "avg_launch_ms": avg_ms,
-                     "flops_per_launch": gram_flops,
+                     "flops_per_launch": gram_flops, "feature_pair_classes": NX,
                      "dense_equivalent_tflops": 2.0 * S_local * D * D / (avg_ms * 1e-3) * 1e-12},
     }
     if rank == 0 and world == 1 and not args.no_variants:

@@ -81,10 +81,16 @@ int ttk_hess_left_f64(const double* H, const double* L, double* HL, int64_t S, i
  *   ttk_gram_scale_f64  -> scale[0] = mean_i |A_ii| (1 if 0)      (network.py:298-300)
  *   ttk_gram_expand_f64 -> A_out (D,D) = A / scale[0] + ridge*I   (network.py:301,308,312)
  *                          (scale == NULL means 1).
- * sym_left != 0 asserts H[s] symmetric (exploits l<->m symmetry). */
+ * sym_left != 0 asserts H[s] symmetric (exploits l<->m symmetry).
+ * x_pair_rep (HOST array of p(p+1)/2 ints, or NULL) names feature-pair classes: entry b, for
+ * the pair (i<=j) at upper-triangle row-major position b, is the position of an earlier pair
+ * (or b itself) whose product X_i X_j equals this pair's for every sample - e.g. a
+ * polynomial basis X_i = x^i (models/tnml.py:11-17) has X_i X_j = x^(i+j).  Only one slice of
+ * the Gram per class is computed and the others are copies; the caller vouches for the
+ * equality.  Honoured for p <= 10, ignored (everything computed) above. */
 int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left);
 int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R,
-                 int64_t S, int C, int rl, int p, int rr, int sym_left,
+                 int64_t S, int C, int rl, int p, int rr, int sym_left, const int* x_pair_rep,
                  void* ws, int64_t ws_bytes, void* stream);
 int ttk_gram_scale_f64(const void* ws, int rl, int p, int rr, int sym_left, double* scale, void* stream);
 int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, const double* scale,

@@ -304,13 +304,20 @@ __host__ __device__ __forceinline__ int tri_index(int i, int j, int n) {  // req
   return i * n - (i * (i - 1)) / 2 + (j - i);
 }
 
+#define GRAM_MAX_CLASSED 64   // pair classes are honoured up to this many (p,q) pairs (p <= 10)
 struct GramDims {
   int MP, MPpad, NX, NR, NRpad, ntm, ntn, nbp, ntiles, ngroups, nslabs, CH;
   int64_t slab_len, gsize;
+  // Feature-pair classes: pairs (p,q) whose products X_p X_q coincide for every sample (e.g.
+  // powers of one variable: X_p X_q = x^(p+q)) share one slice of the Gram.  Only the nrep
+  // representatives reps[] are computed; repof[b] names the representative of pair b.
+  int nrep, classed;
+  int reps[GRAM_MAX_CLASSED], repof[GRAM_MAX_CLASSED];
 };
 
-static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym) {
+static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym, int nrep = 0) {
   GramDims d;
+  d.classed = 0;
   d.MP = sym ? rl * (rl + 1) / 2 : rl * rl;
   d.MPpad = round_up(d.MP, 48);
   d.NX = p * (p + 1) / 2;
@@ -318,7 +325,8 @@ static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym) {
   d.NRpad = round_up(d.NR, 48);
   d.ntm = d.MPpad / 48;
   d.ntn = d.NRpad / 48;
-  d.nbp = (d.NX + 1) / 2;              // a wave tile carries two (p,q) pairs
+  d.nrep = nrep > 0 ? nrep : d.NX;
+  d.nbp = (d.nrep + 1) / 2;            // a wave tile carries two (p,q) pairs
   d.ntiles = d.nbp * d.ntm * d.ntn;
   d.ngroups = (d.ntiles + 3) / 4;
   d.gsize = (int64_t)d.MPpad * d.NX * d.NRpad;
@@ -423,10 +431,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
     tm = rem / gd.ntn;
     tn = rem - tm * gd.ntn;
   }
-  const int b0 = 2 * bp, b1 = 2 * bp + 1;
+  const bool has1 = 2 * bp + 1 < gd.nrep;
+  const int b0 = gd.classed ? gd.reps[2 * bp] : 2 * bp;
+  const int b1 = has1 ? (gd.classed ? gd.reps[2 * bp + 1] : 2 * bp + 1) : 0;
   // element offsets inside a sample row of the chunk image; W - 1 is the zero column
   const int oX0 = 2 * CW + b0;
-  const int oX1 = b1 < gd.NX ? 2 * CW + b1 : W - 1;
+  const int oX1 = has1 ? 2 * CW + b1 : W - 1;
   int oH[3], oL[3], oR1[3], oR2[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
           const int a = tm * 48 + u * 16 + kq + 4 * t;
           const int c = tn * 48 + v * 16 + i;
           dst[((int64_t)a * gd.NX + b0) * gd.NRpad + c] = acc[0][u][v][t];
-          if (b1 < gd.NX) dst[((int64_t)a * gd.NX + b1) * gd.NRpad + c] = acc[1][u][v][t];
+          if (has1) dst[((int64_t)a * gd.NX + b1) * gd.NRpad + c] = acc[1][u][v][t];
         }
   }
 }
@@ -533,6 +543,20 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restr
   if (idx >= n) return;
   double acc = accumulate ? out[idx] : 0.0;
   for (int k = 0; k < nslabs; ++k) acc += partial[(int64_t)k * stride + idx];
+  out[idx] = acc;
+}
+
+// Slab reduction of a classed Gram: slice b of the result is the sum over slabs of the slice of
+// its representative (with one slab and partial == out this only replicates, in place: a
+// representative's slice is rewritten with its own value).
+__global__ __launch_bounds__(256) void gram_reduce_classed_kernel(const double* __restrict__ partial, int nslabs,
+                                                                   int64_t stride, GramDims gd, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= gd.gsize) return;
+  const int b = (int)((idx / gd.NRpad) % gd.NX);
+  const int64_t src = idx + (int64_t)(gd.repof[b] - b) * gd.NRpad;
+  double acc = 0.0;
+  for (int k = 0; k < nslabs; ++k) acc += partial[(int64_t)k * stride + src];
   out[idx] = acc;
 }
 
@@ -1486,15 +1510,40 @@ int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left)
   if (S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const GramDims d = gram_dims(S, C, rl, p, rr, sym_left);
   if (d.CH < 4) return TTK_EINVAL;
+  // the slab count depends on how many pair classes a call names: size for the worst case
+  int nslabs = d.nslabs;
+  if (d.NX <= GRAM_MAX_CLASSED)
+    for (int nrep = 1; nrep < d.NX; ++nrep) {
+      const int ns = gram_dims(S, C, rl, p, rr, sym_left, nrep).nslabs;
+      if (ns > nslabs) nslabs = ns;
+    }
   const int64_t W = 2 * (int64_t)C * rl + d.NX + rr + 1;
-  return ((int64_t)(1 + (d.nslabs > 1 ? d.nslabs : 0)) * d.gsize + S * W) * (int64_t)sizeof(double);
+  return ((int64_t)(1 + (nslabs > 1 ? nslabs : 0)) * d.gsize + S * W) * (int64_t)sizeof(double);
 }
 
 int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R, int64_t S, int C, int rl, int p,
-                 int rr, int sym_left, void* ws, int64_t ws_bytes, void* stream) {
+                 int rr, int sym_left, const int* x_pair_rep, void* ws, int64_t ws_bytes, void* stream) {
   if (!L || !H || !X || !R || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
-  const GramDims d = gram_dims(S, C, rl, p, rr, sym_left);
+  const int NX = p * (p + 1) / 2;
+  int nrep = 0;
+  if (x_pair_rep && NX <= GRAM_MAX_CLASSED) {
+    for (int b = 0; b < NX; ++b) {
+      const int r = x_pair_rep[b];
+      if (r < 0 || r > b || x_pair_rep[r] != r) return TTK_EINVAL;
+      if (r == b) ++nrep;
+    }
+    if (nrep == NX) nrep = 0;
+  }
+  GramDims d = gram_dims(S, C, rl, p, rr, sym_left, nrep);
   if (d.CH < 4) return TTK_EINVAL;
+  if (nrep) {
+    d.classed = 1;
+    int k = 0;
+    for (int b = 0; b < NX; ++b) {
+      d.repof[b] = x_pair_rep[b];
+      if (x_pair_rep[b] == b) d.reps[k++] = b;
+    }
+  }
   if (ws_bytes < ttk_gram_ws_bytes(S, C, rl, p, rr, sym_left)) return TTK_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* G = (double*)ws;
@@ -1516,7 +1565,11 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   if (timed) (void)hipEventRecord(g_ev_stop[g_ev_count++], st);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
-  if (d.nslabs > 1) {
+  if (d.classed) {
+    hipLaunchKernelGGL(gram_reduce_classed_kernel, dim3((unsigned)((d.gsize + 255) / 256)), dim3(256), 0, st,
+                       (const double*)partial, d.nslabs, d.gsize, d, G);
+    rc = ttk_launch_status();
+  } else if (d.nslabs > 1) {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((d.gsize + 255) / 256)), dim3(256), 0, st, partial,
                        d.nslabs, d.gsize, d.gsize, G, 0);
     rc = ttk_launch_status();

@@ -1,5 +1,7 @@
 """torch.Tensor front-ends of the C ABI: argument checks, output allocation,
 current-stream plumbing.  No arithmetic happens here."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -148,14 +150,21 @@ class GramWorkspace:
         return self.buf[:self.gsize]
 
 
-def gram(L, H, X, R, sym=True, ws=None):
-    """Compressed Gram of the local normal equations (H = per-sample Hessian (S,C,C)) -> GramWorkspace."""
+def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
+    """Compressed Gram of the local normal equations (H = per-sample Hessian (S,C,C)) -> GramWorkspace.
+    pair_rep: feature-pair classes as returned by pair_classes(X) (None: every pair computed)."""
     S, C, rl = L.shape
     p, rr = X.shape[1], R.shape[1]
     if ws is None or ws.dims != (S, C, rl, p, rr, int(bool(sym))):
         ws = GramWorkspace(S, C, rl, p, rr, sym, L.device)
+    rep = None
+    if pair_rep is not None:
+        if len(pair_rep) != p * (p + 1) // 2:
+            raise _lib.TTKError("pair_rep: expected one entry per feature pair")
+        rep = (ctypes.c_int * len(pair_rep))(*[int(v) for v in pair_rep])
     rc = _lib.lib().ttk_gram_f64(_chk(L, "L"), _chk(H, "H", (S, C, C)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
-                                 S, C, rl, p, rr, int(bool(sym)), ws.buf.data_ptr(), ws.nbytes, _stream(L))
+                                 S, C, rl, p, rr, int(bool(sym)), None if rep is None else ctypes.cast(rep, ctypes.c_void_p),
+                                 ws.buf.data_ptr(), ws.nbytes, _stream(L))
     _lib.check(rc, "ttk_gram_f64")
     return ws
 

@@ -55,6 +55,40 @@ def _changed(seen, node):
     return seen is None or seen[0] is not t or seen[1] != t._version
 
 
+PAIR_CLASS_MAX_P = 10      # the library honours pair classes up to p(p+1)/2 <= 64 pairs
+PAIR_CLASS_TOL = 16.0      # products that agree to this many ulps (of the column's largest entry) are one class
+
+
+def pair_classes(X):
+    """Classes of feature pairs (i<=j, upper-triangle row-major) whose products X_i X_j coincide on
+    every sample, as the list rep[b] = first pair of b's class; None when all pairs differ or p is
+    above the limit.  A polynomial basis X_i = x^i gives the p(p+1)/2 pairs 2p-1 classes (i+j).
+    Candidates come from a strided subset of the samples and are then checked on all of them."""
+    S, p = X.shape
+    if p < 2 or p > PAIR_CLASS_MAX_P or S == 0:
+        return None
+    iu = torch.triu_indices(p, p, device=X.device)
+    XX = X[:, iu[0]] * X[:, iu[1]]                            # (S, NX), same pair order as the kernels
+    NX = XX.shape[1]
+    tol = PAIR_CLASS_TOL * torch.finfo(XX.dtype).eps
+    big = XX.abs().amax(dim=0)
+    sub = XX[::max(1, S // 1024)][:2048]
+    diff = (sub.unsqueeze(2) - sub.unsqueeze(1)).abs().amax(dim=0)
+    same = (diff <= tol * torch.maximum(big.unsqueeze(0), big.unsqueeze(1))).cpu()
+    rep = list(range(NX))
+    for b in range(NX):
+        for a in range(b):
+            if rep[a] == a and bool(same[a, b]):
+                rep[b] = a
+                break
+    if all(rep[b] == b for b in range(NX)):
+        return None
+    rt = torch.tensor(rep, device=X.device)
+    ok = ((XX - XX[:, rt]).abs().amax(dim=0) <= tol * big).cpu()
+    rep = [rep[b] if bool(ok[b]) else b for b in range(NX)]
+    return None if all(rep[b] == b for b in range(NX)) else rep
+
+
 class LocalProblem:
     """The normal equations of one train node for a bound data set.
 
@@ -156,6 +190,7 @@ class EngineBase:
         self.datasets = []
         self._gram_ws = {}
         self._abuf = {}
+        self._pairs = {}
 
     def data_for(self, x, shard=None):
         raw = self.site_list(x)
@@ -182,9 +217,18 @@ class EngineBase:
         ws = self._gram_ws.get(key)
         if ws is None:
             self._gram_ws.clear()
-        ws = ops.gram(L, H, X, R, sym=sym, ws=ws)
+        ws = ops.gram(L, H, X, R, sym=sym, ws=ws, pair_rep=self.pair_rep(X))
         self._gram_ws[key] = ws
         return ws
+
+    def pair_rep(self, X):
+        """Feature-pair classes of a feature matrix, detected once per tensor (and version)."""
+        key = (X.data_ptr(), tuple(X.shape), X._version)
+        if key not in self._pairs:
+            if len(self._pairs) > 256:
+                self._pairs.clear()
+            self._pairs[key] = pair_classes(X)
+        return self._pairs[key]
 
     def dense_buffer(self, D, device):
         buf = self._abuf.get(D)

@@ -57,7 +57,7 @@ class _WS:
         return self.A
 
 
-def gram(L, H, X, R, sym=True, ws=None):
+def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
     S, C, rl = L.shape
     J = kr_rows(L, X, R)
     A = torch.einsum('scd,sce,sef->df', J, H, J)

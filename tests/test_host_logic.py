@@ -116,3 +116,19 @@ def test_split_matches_reference_split():
     idx = np.arange(X.shape[0])
     np.random.RandomState(42).shuffle(idx)
     assert torch.equal(Xt, X[idx[:360]]) and torch.equal(Xv, X[idx[360:]])
+
+
+def test_feature_pair_classes_detection():
+    from tensornetworksfork_amd.tensor.engine import pair_classes
+    torch.manual_seed(0)
+    x = torch.rand(500, dtype=torch.float64) * 2 - 1
+    X = torch.stack([x ** d for d in range(6)], dim=-1)
+    rep = pair_classes(X)
+    iu = torch.triu_indices(6, 6)
+    sums = (iu[0] + iu[1]).tolist()
+    assert rep is not None and len(set(rep)) == 11
+    assert all(sums[b] == sums[rep[b]] and rep[b] <= b and rep[rep[b]] == rep[b] for b in range(21))
+    assert pair_classes(torch.rand(500, 5, dtype=torch.float64)) is None
+    sc = torch.stack([torch.cos(x), torch.sin(x)], dim=-1)
+    assert pair_classes(sc) is None
+    assert pair_classes(torch.rand(50, 12, dtype=torch.float64)) is None      # above the class limit: not attempted

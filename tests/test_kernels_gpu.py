@@ -172,3 +172,29 @@ def test_qr_matches_lapack(m, n):
     assert G.rel_err(Q, Qr) < 1e-10
     assert G.rel_err(R, Rr) < 1e-10
     assert G.rel_err(Q.cpu() @ R.cpu(), A) < 1e-12
+
+
+@gpu
+def test_gram_feature_pair_classes():
+    """Polynomial features: the classed Gram (one slice per value of p+q) equals the full one."""
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor.engine import pair_classes
+    dev = _dev()
+    S, C, rl, p, rr = 3000, 2, 5, 5, 6
+    x = torch.rand(S, dtype=torch.float64, device=dev) * 2 - 1
+    X = torch.stack([x ** d for d in range(p)], dim=-1).contiguous()
+    rep = pair_classes(X)
+    assert rep is not None and len(set(rep)) == 2 * p - 1
+    L, R = _rand((S, C, rl), 1).to(dev), _rand((S, rr), 2).to(dev)
+    Hs = _rand((S, C, C), 3).to(dev)
+    H = (Hs @ Hs.transpose(1, 2)).contiguous()
+    full = ops.gram_expand(ops.gram(L, H, X, R, sym=True))
+    classed = ops.gram_expand(ops.gram(L, H, X, R, sym=True, pair_rep=rep))
+    assert ((classed - full).abs().max() / full.abs().max()).item() < 1e-13
+    big = ops.gram_expand(ops.gram(L[:40].contiguous(), H[:40].contiguous(), X[:40].contiguous(), R[:40].contiguous(),
+                                   sym=False, pair_rep=rep))       # one slab: in-place replication
+    ref = ops.gram_expand(ops.gram(L[:40].contiguous(), H[:40].contiguous(), X[:40].contiguous(), R[:40].contiguous(),
+                                   sym=False))
+    assert ((big - ref).abs().max() / ref.abs().max()).item() < 1e-13
+    with pytest.raises(Exception):
+        ops.gram(L, H, X, R, sym=True, pair_rep=[1] + list(range(1, p * (p + 1) // 2)))   # rep must not point forward
