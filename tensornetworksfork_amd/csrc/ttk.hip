@@ -410,6 +410,41 @@ __device__ __forceinline__ void gram_chunk_load(const double* __restrict__ g, in
   }
 }
 
+// The products of one staged chunk for one wave tile: per group of 4 samples the operands
+// P[a] = H_l L_m (x XX_b) and Q[c] = R_r R_t are formed from the chunk image and multiplied
+// on the matrix cores.  TWO = the tile carries two (p,q) pairs that share P and Q.
+template <bool C1, bool TWO>
+__device__ __forceinline__ void gram_steps(const double* __restrict__ smem, int steps, int kq, int W, int C, int rl,
+                                           int oX0, int oX1, const int (&oH)[3], const int (&oL)[3],
+                                           const int (&oR1)[3], const int (&oR2)[3], d4 (&acc)[2][3][3]) {
+  for (int ks = 0; ks < steps; ++ks) {
+    const double* row = smem + (ks * 4 + kq) * W;
+    const double xx0 = row[oX0], xx1 = TWO ? row[oX1] : 0.0;
+    double aop0[3], aop1[3], bop[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      double pa;
+      if (C1) {
+        pa = row[oH[u]] * row[oL[u]];
+      } else {
+        pa = 0.0;
+        if (oL[u] != W - 1)
+          for (int d = 0; d < C; ++d) pa += row[oH[u] + d * rl] * row[oL[u] + d * rl];
+      }
+      aop0[u] = pa * xx0;
+      if (TWO) aop1[u] = pa * xx1;
+      bop[u] = row[oR1[u]] * row[oR2[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        acc[0][u][v] = MFMA_F64(aop0[u], bop[v], acc[0][u][v]);
+        if (TWO) acc[1][u][v] = MFMA_F64(aop1[u], bop[v], acc[1][u][v]);
+      }
+  }
+}
+
 template <bool C1>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ F, int64_t S, int C, int rl, int p,
                                                        int rr, int sym, GramDims gd, double* __restrict__ partial) {
@@ -491,32 +526,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
       gram_chunk_load(F + (c0 + CH) * W, (int)min((int64_t)CH, s_end - c0 - CH) * W, tid, pre);
     if (active) {
       const int steps = (int)((nvalid + 3) >> 2);
-      for (int ks = 0; ks < steps; ++ks) {
-        const double* row = smem + (ks * 4 + kq) * W;
-        const double xx0 = row[oX0], xx1 = row[oX1];
-        double aop0[3], aop1[3], bop[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          double pa;
-          if (C1) {
-            pa = row[oH[u]] * row[oL[u]];
-          } else {
-            pa = 0.0;
-            if (oL[u] != W - 1)
-              for (int d = 0; d < C; ++d) pa += row[oH[u] + d * rl] * row[oL[u] + d * rl];
-          }
-          aop0[u] = pa * xx0;
-          aop1[u] = pa * xx1;
-          bop[u] = row[oR1[u]] * row[oR2[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-          for (int v = 0; v < 3; ++v) {
-            acc[0][u][v] = MFMA_F64(aop0[u], bop[v], acc[0][u][v]);
-            acc[1][u][v] = MFMA_F64(aop1[u], bop[v], acc[1][u][v]);
-          }
-      }
+      if (has1)
+        gram_steps<C1, true>(smem, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
+      else   // the last, unpaired (p,q) of an odd count: half the products
+        gram_steps<C1, false>(smem, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
     }
   }
   if (active) {
@@ -1323,88 +1336,72 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   const int ldm = m + 1;
   double* A = smem;                 // A[c * ldm + r]
   double* tau = A + (size_t)n * ldm;
-  double* red = tau + k;            // 4 partial sums + broadcast slots
-  double* wv = red + 8;             // w[c] = v^T A[:,c], n entries
+  double* Qw = tau + k + 8 + n;     // Qw[c * ldm + r], m x k
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int idx = tid; idx < m * n; idx += 256) {
     const int r = idx / n, c = idx - r * n;
     A[c * ldm + r] = Ain[idx];
   }
   __syncthreads();
+  // Columns are dealt to the four waves (c mod 4).  The owner of column j forms its reflector
+  // (wave-level reduction), one barrier publishes it, then every wave applies it to its own
+  // columns: dot product and update stay inside the wave, so a step costs one barrier.
   for (int j = 0; j < k; ++j) {
-    // ||x||^2 of A[j+1:, j]
-    double part = 0.0;
-    for (int r = j + 1 + tid; r < m; r += 256) part += A[j * ldm + r] * A[j * ldm + r];
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
-      const double xn2 = red[0] + red[1] + red[2] + red[3];
-      const double alpha = A[j * ldm + j];
+    double* vj = A + (size_t)j * ldm;
+    if (wave == (j & 3)) {
+      double part = 0.0;
+      for (int r = j + 1 + lane; r < m; r += 64) part += vj[r] * vj[r];
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      const double alpha = vj[j];
       double t = 0.0, beta = alpha, scale = 0.0;
-      if (xn2 != 0.0) {
-        const double nrm = sqrt(alpha * alpha + xn2);
+      if (part != 0.0) {
+        const double nrm = sqrt(alpha * alpha + part);
         beta = alpha >= 0.0 ? -nrm : nrm;
         t = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
       }
-      tau[j] = t;
-      red[4] = scale;
-      red[5] = beta;
+      for (int r = j + 1 + lane; r < m; r += 64) vj[r] *= scale;
+      if (lane == 0) {
+        tau[j] = t;
+        vj[j] = beta;
+      }
     }
     __syncthreads();
-    const double scale = red[4], t = tau[j];
-    for (int r = j + 1 + tid; r < m; r += 256) A[j * ldm + r] *= scale;
-    __syncthreads();
-    // w[c] = v^T A[:, c] for c > j (v[j] = 1), one wave per column
-    for (int c = j + 1 + wave; c < n; c += 4) {
+    const double t = tau[j];
+    int c = j + 1 + ((wave - (j + 1)) & 3);   // first own column right of j
+    for (; c < n; c += 4) {
+      double* ac = A + (size_t)c * ldm;
       double acc = 0.0;
-      for (int r = j + 1 + lane; r < m; r += 64) acc += A[j * ldm + r] * A[c * ldm + r];
+      for (int r = j + 1 + lane; r < m; r += 64) acc += vj[r] * ac[r];
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (lane == 0) wv[c] = acc + A[c * ldm + j];
+      const double w = t * (acc + ac[j]);
+      for (int r = j + 1 + lane; r < m; r += 64) ac[r] -= vj[r] * w;
+      if (lane == 0) ac[j] -= w;
     }
-    __syncthreads();
-    // A[:, c] -= tau * v * w[c]
-    const int ncol = n - j - 1, nrow = m - j;
-    for (int idx = tid; idx < ncol * nrow; idx += 256) {
-      const int c = j + 1 + idx / nrow, r = j + idx % nrow;
-      const double v = (r == j) ? 1.0 : A[j * ldm + r];
-      A[c * ldm + r] -= t * v * wv[c];
-    }
-    if (tid == 0) A[j * ldm + j] = red[5];
-    __syncthreads();
   }
+  __syncthreads();
   // R (k x n, upper triangular)
   for (int idx = tid; idx < k * n; idx += 256) {
     const int r = idx / n, c = idx - r * n;
     Rout[idx] = (r <= c) ? A[c * ldm + r] : 0.0;
   }
-  __syncthreads();
-  // Q = H_1 ... H_k I[:, :k], built in place of the reflectors from the last one backwards
-  // (dorg2r): column j of the work array holds v_j below the diagonal.
-  double* Qw = wv + n;   // Qw[c * ldm + r], m x k
-  for (int idx = tid; idx < m * k; idx += 256) {
-    const int c = idx / m, r = idx - c * m;
-    Qw[c * ldm + r] = (r == c) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  for (int j = k - 1; j >= 0; --j) {
-    const double t = tau[j];
-    for (int c = j + wave; c < k; c += 4) {
+  // Q = H_1 ... H_k I[:, :k] (dorg2r).  Column c of the identity is touched by H_j only for
+  // j <= c, and the columns are independent: each wave runs its own columns through their
+  // reflectors from the last one backwards, no barrier.
+  for (int c = wave; c < k; c += 4) {
+    double* qc = Qw + (size_t)c * ldm;
+    for (int r = lane; r < m; r += 64) qc[r] = (r == c) ? 1.0 : 0.0;
+    for (int j = c; j >= 0; --j) {
+      const double* vj = A + (size_t)j * ldm;
       double acc = 0.0;
-      for (int r = j + 1 + lane; r < m; r += 64) acc += A[j * ldm + r] * Qw[c * ldm + r];
+      for (int r = j + 1 + lane; r < m; r += 64) acc += vj[r] * qc[r];
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (lane == 0) wv[c] = acc + Qw[c * ldm + j];
+      const double w = tau[j] * (acc + qc[j]);
+      for (int r = j + 1 + lane; r < m; r += 64) qc[r] -= vj[r] * w;
+      if (lane == 0) qc[j] -= w;
     }
-    __syncthreads();
-    const int ncol = k - j, nrow = m - j;
-    for (int idx = tid; idx < ncol * nrow; idx += 256) {
-      const int c = j + idx / nrow, r = j + idx % nrow;
-      const double v = (r == j) ? 1.0 : A[j * ldm + r];
-      Qw[c * ldm + r] -= t * v * wv[c];
-    }
-    __syncthreads();
   }
+  __syncthreads();
   for (int idx = tid; idx < m * k; idx += 256) {
     const int r = idx / k, c = idx - r * k;
     Q[idx] = Qw[c * ldm + r];

@@ -68,12 +68,13 @@ def pair_classes(X):
     if p < 2 or p > PAIR_CLASS_MAX_P or S == 0:
         return None
     iu = torch.triu_indices(p, p, device=X.device)
-    XX = X[:, iu[0]] * X[:, iu[1]]                            # (S, NX), same pair order as the kernels
-    NX = XX.shape[1]
+    Xt = X.T.contiguous()                                      # reductions run along contiguous rows
+    XX = Xt[iu[0]] * Xt[iu[1]]                                 # (NX, S), same pair order as the kernels
+    NX = XX.shape[0]
     tol = PAIR_CLASS_TOL * torch.finfo(XX.dtype).eps
-    big = XX.abs().amax(dim=0)
-    sub = XX[::max(1, S // 1024)][:2048]
-    diff = (sub.unsqueeze(2) - sub.unsqueeze(1)).abs().amax(dim=0)
+    sub = XX[:, ::max(1, S // 1024)][:, :2048]
+    big = sub.abs().amax(dim=1)
+    diff = (sub.unsqueeze(1) - sub.unsqueeze(0)).abs().amax(dim=2)
     same = (diff <= tol * torch.maximum(big.unsqueeze(0), big.unsqueeze(1))).cpu()
     rep = list(range(NX))
     for b in range(NX):
@@ -84,7 +85,7 @@ def pair_classes(X):
     if all(rep[b] == b for b in range(NX)):
         return None
     rt = torch.tensor(rep, device=X.device)
-    ok = ((XX - XX[:, rt]).abs().amax(dim=0) <= tol * big).cpu()
+    ok = ((XX - XX[rt]).abs().amax(dim=1) <= tol * XX.abs().amax(dim=1)).cpu()
     rep = [rep[b] if bool(ok[b]) else b for b in range(NX)]
     return None if all(rep[b] == b for b in range(NX)) else rep
 
