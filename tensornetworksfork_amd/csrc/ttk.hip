@@ -47,15 +47,19 @@ __global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict_
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
   double* Ew = Es + wave * e * 16;
   double* Xw = Xs + wave * p * 16;
+  // rows past the end are clamped, not predicated (a load under a per-element branch is waited
+  // for one by one); they are zeroed after the load and never stored
   for (int idx = lane; idx < 16 * e; idx += 64) {
     const int ii = idx & 15, l = idx >> 4;
     const int64_t row = row0 + ii;
-    Ew[l * 16 + ii] = row < M ? E[row * e + l] : 0.0;
+    const double v = E[min(row, M - 1) * e + l];
+    Ew[l * 16 + ii] = row < M ? v : 0.0;
   }
   for (int idx = lane; idx < 16 * p; idx += 64) {
     const int ii = idx & 15, pp = idx >> 4;
     const int64_t row = row0 + ii;
-    Xw[pp * 16 + ii] = row < M ? X[(row / C) * p + pp] : 0.0;
+    const double v = X[(min(row, M - 1) / C) * p + pp];
+    Xw[pp * 16 + ii] = row < M ? v : 0.0;
   }
   d4 acc[4];
 #pragma unroll
@@ -70,12 +74,14 @@ __global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict_
         k = idx / npad;
         nn = idx - k * npad;
         const int kk = kc0 + k;
-        if (kk < K && nn < nloc) v = core[(int64_t)kk * n + nb0 + nn];
+        v = core[(int64_t)min(kk, K - 1) * n + nb0 + min(nn, nloc - 1)];
+        if (kk >= K || nn >= nloc) v = 0.0;
       } else {
         nn = idx / KC;
         k = idx - nn * KC;
         const int kk = kc0 + k;
-        if (kk < K && nn < nloc) v = core[(int64_t)(nb0 + nn) * K + kk];
+        v = core[(int64_t)(nb0 + min(nn, nloc - 1)) * K + min(kk, K - 1)];
+        if (kk >= K || nn >= nloc) v = 0.0;
       }
       Bs[k * 64 + nn] = v;
     }
@@ -559,6 +565,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restr
   out[idx] = acc;
 }
 
+// The same sum for many slabs and few outputs (the right-hand side: hundreds of slabs of a few
+// thousand numbers): 16 outputs x 16 slab groups per workgroup, every thread's loads
+// independent and in flight together, the 16 group sums added in fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const double* __restrict__ partial, int nslabs,
+                                                                 int64_t stride, int64_t n, double* __restrict__ out,
+                                                                 int accumulate) {
+  __shared__ double part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
+  const int64_t src = idx < n ? idx : n - 1;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = g;
+  for (; k + 48 < nslabs; k += 64) {
+    a0 += partial[(int64_t)k * stride + src];
+    a1 += partial[(int64_t)(k + 16) * stride + src];
+    a2 += partial[(int64_t)(k + 32) * stride + src];
+    a3 += partial[(int64_t)(k + 48) * stride + src];
+  }
+  for (; k < nslabs; k += 16) a0 += partial[(int64_t)k * stride + src];
+  part[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && idx < n) {
+    double acc = accumulate ? out[idx] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += part[q][o];
+    out[idx] = acc;
+  }
+}
+
 // Slab reduction of a classed Gram: slice b of the result is the sum over slabs of the slice of
 // its representative (with one slab and partial == out this only replicates, in place: a
 // representative's slice is rewritten with its own value).
@@ -687,19 +722,24 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ L, 
     for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
       const int64_t nvalid = min((int64_t)CH, s_end - c0);
       __syncthreads();
+      // clamped, unconditional loads (samples past the slab end repeat the last one and are zeroed)
       for (int idx = threadIdx.x; idx < CH * rl; idx += 256) {
         const int sl = idx / rl, l = idx - sl * rl;
+        const int64_t s = c0 + min((int64_t)sl, nvalid - 1);
         double v = 0.0;
-        if (sl < nvalid) {
-          const int64_t s = c0 + sl;
-          for (int c = 0; c < C; ++c) v += g[s * C + c] * L[(s * C + c) * rl + l];
-        }
-        GLs[idx] = v;
+        for (int c = 0; c < C; ++c) v += g[s * C + c] * L[(s * C + c) * rl + l];
+        GLs[idx] = sl < nvalid ? v : 0.0;
       }
       const double* gX = X + c0 * p;
-      for (int idx = threadIdx.x; idx < CH * p; idx += 256) Xs[idx] = idx < nvalid * p ? gX[idx] : 0.0;
+      for (int idx = threadIdx.x; idx < CH * p; idx += 256) {
+        const double v = gX[min((int64_t)idx, nvalid * p - 1)];
+        Xs[idx] = idx < nvalid * p ? v : 0.0;
+      }
       const double* gR = R + c0 * rr;
-      for (int idx = threadIdx.x; idx < CH * rr; idx += 256) Rs[idx] = idx < nvalid * rr ? gR[idx] : 0.0;
+      for (int idx = threadIdx.x; idx < CH * rr; idx += 256) {
+        const double v = gR[min((int64_t)idx, nvalid * rr - 1)];
+        Rs[idx] = idx < nvalid * rr ? v : 0.0;
+      }
       __syncthreads();
       const int steps = (int)((nvalid + 3) >> 2);
       for (int ks = 0; ks < steps; ++ks) {
@@ -1688,8 +1728,12 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
                      (double*)ws);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)ws,
-                     d.nslabs, D, D, b, accumulate);
+  if (d.nslabs > 32)
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)ws,
+                       d.nslabs, D, D, b, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)ws,
+                       d.nslabs, D, D, b, accumulate);
   return ttk_launch_status();
 }
 
