@@ -132,6 +132,11 @@ def gram_gsize(rl, p, rr, sym):
     return up48(mp) * (p * (p + 1) // 2) * up48(rr * (rr + 1) // 2)
 
 
+def gram_supported(S, C, rl, p, rr, sym=True):
+    """Whether ttk_gram_f64 accepts these extents (its packed per-sample row must fit an LDS chunk)."""
+    return int(_lib.lib().ttk_gram_ws_bytes(int(S), int(C), int(rl), int(p), int(rr), int(bool(sym)))) > 0
+
+
 class GramWorkspace:
     """Symmetry-compressed Gram matrix held in a device workspace."""
 

@@ -90,6 +90,23 @@ def pair_classes(X):
     return None if all(rep[b] == b for b in range(NX)) else rep
 
 
+def _xt_times(X, W, chunk=1024):
+    """X^T W for tall X (S,p), W (S,n): the library GEMM has no split over the long contraction, so
+    the samples are cut into chunks, multiplied as one batched GEMM and the partial products added."""
+    S = X.shape[0]
+    nk = S // chunk
+    if nk < 2:
+        return X.T @ W
+    S0 = nk * chunk
+    out = torch.bmm(X[:S0].reshape(nk, chunk, -1).transpose(1, 2), W[:S0].reshape(nk, chunk, -1)).sum(dim=0)
+    if S0 < S:
+        out = out + X[S0:].T @ W[S0:]
+    return out
+
+
+TWO_STAGE_MIN_P = 16    # from this many features on, J v and J^T g contract the features first (library GEMM)
+
+
 class LocalProblem:
     """The normal equations of one train node for a bound data set.
 
@@ -107,26 +124,52 @@ class LocalProblem:
         self.back = back
         self.terms = terms
         self.J = J
+        self._Jt = None
 
     # -- first order
+    def _jt(self):
+        """(D, S*C) copy of the explicit rows: sums over samples then run along contiguous memory."""
+        if self._Jt is None:
+            self._Jt = self.J.reshape(self.S * self.C, self.D).T.contiguous()
+        return self._Jt
+
     def rhs(self, g):
         """b = J^T g, canonical shape."""
         if self.J is not None:
-            return (self.J.reshape(self.S * self.C, self.D).T @ g.reshape(self.S * self.C)).reshape(self.shape)
+            # a few dozen columns against half a million rows: element-wise product + row sums run at
+            # memory speed, the library's matrix-vector kernels do not
+            return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
         for (L, X, R) in self.terms:
-            out = ops.rhs(L, X, R, g) if out is None else ops.rhs(L, X, R, g, out=out)
+            if X.shape[1] >= TWO_STAGE_MIN_P:
+                # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L : one plain GEMM over the samples
+                S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
+                GL = (g.unsqueeze(2) * L).sum(dim=1)                                     # (S, rl)
+                W = (GL.unsqueeze(2) * R.unsqueeze(1)).reshape(S, rl * rr)
+                bt = _xt_times(X, W).reshape(X.shape[1], rl, rr).permute(1, 0, 2)
+                out = bt.contiguous() if out is None else out.add_(bt)
+            else:
+                out = ops.rhs(L, X, R, g) if out is None else ops.rhs(L, X, R, g, out=out)
         return out
 
     def jv(self, v):
         """u[s,c] = J v."""
         if self.J is not None:
-            return (self.J.reshape(self.S * self.C, self.D) @ v.reshape(self.D)).reshape(self.S, self.C)
+            return (self._jt() * v.reshape(self.D, 1)).sum(dim=0).reshape(self.S, self.C)
         v = v.reshape(self.shape)
         u = None
         tmp = {}
-        for (L, X, R) in self.terms:     # terms that share R share one environment-step buffer
-            key = id(R)
+        for (L, X, R) in self.terms:
+            if X.shape[1] >= TWO_STAGE_MIN_P:
+                # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (plain GEMM shared by
+                # the C outputs of a sample), then the two environments: C*p/(C+p) times fewer FLOPs
+                S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
+                T = X @ v.permute(1, 0, 2).reshape(X.shape[1], rl * rr)                 # (S, rl*rr)
+                z = (T.reshape(S, rl, rr) * R.unsqueeze(1)).sum(dim=2)                   # (S, rl)
+                t = (L * z.unsqueeze(1)).sum(dim=2)                                      # (S, C)
+                u = t if u is None else u.add_(t)
+                continue
+            key = id(R)                  # terms that share R share one environment-step buffer
             if key in tmp:
                 ops.env_step_left(L, X, v, out=tmp[key][0])
             else:
@@ -137,13 +180,13 @@ class LocalProblem:
 
     def matvec_fn(self, H):
         """v -> (J^T H J) v, canonical shape, never forming the Gram matrix."""
-        if self.terms is not None and len(self.terms) == 1:
+        if self.terms is not None and len(self.terms) == 1 and self.terms[0][1].shape[1] < TWO_STAGE_MIN_P:
             L, X, R = self.terms[0]
             return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
         def mv(v):
             u = self.jv(v)
-            hu = ops.hess_left(H, u.unsqueeze(-1)).squeeze(-1)
+            hu = ops.hess_left(H, u.contiguous().unsqueeze(-1)).squeeze(-1)
             return self.rhs(hu)
         return mv
 
@@ -157,6 +200,15 @@ class LocalProblem:
     # -- Gram
     def single_term(self):
         return self.terms is not None and len(self.terms) == 1
+
+    def compressed_gram(self, sym=True):
+        """True when the symmetry-compressed Gram kernel (and the Cholesky fed from it) takes this
+        problem: one Khatri-Rao term whose packed sample row fits the kernel's LDS chunk (a site with
+        many features, e.g. 50 patches = 1275 feature pairs, does not and goes the dense way)."""
+        if not self.single_term():
+            return False
+        L, X, R = self.terms[0]
+        return ops.gram_supported(self.S, self.C, L.shape[2], X.shape[1], R.shape[1], sym)
 
     def rows(self, lo, hi):
         """Explicit Jacobian rows of samples [lo, hi): (n, C, D)."""
@@ -505,11 +557,20 @@ class ChainEngine(EngineBase):
         """Column k applied to the left environment with `core` in place of A_k: (cb_k, S, C, rr_k)."""
         Lk, G = self.left(d, k), self.feats(d, k)
         ca, cb = G.shape[0], G.shape[1]
+        rl, p, rr = core.shape
+        two_stage = p >= TWO_STAGE_MIN_P      # many features: contract them first (library GEMMs)
+        if two_stage:
+            cm = core.permute(1, 0, 2).reshape(p, rl * rr)
         outs = []
         for b in range(cb):
-            o = ops.env_step_left(Lk[0], G[0, b], core)
-            for a in range(1, ca):
-                ops.env_step_left(Lk[a], G[a, b], core, out=o)
+            o = None
+            for a in range(ca):
+                if two_stage:
+                    t = torch.bmm(Lk[a], (G[a, b] @ cm).reshape(-1, rl, rr))
+                    o = t if o is None else o.add_(t)
+                else:
+                    o = ops.env_step_left(Lk[a], G[a, b], core) if o is None else \
+                        ops.env_step_left(Lk[a], G[a, b], core, out=o)
             outs.append(o)
         return torch.stack(outs) if cb > 1 else outs[0].unsqueeze(0)
 
@@ -522,11 +583,20 @@ class ChainEngine(EngineBase):
             else:
                 Rn, G, core = self.right(d, k + 1), self.feats(d, k + 1), self.canonA(k + 1)
                 ca, cb = G.shape[0], G.shape[1]
+                rl, p, rr = core.shape
+                two_stage = p >= TWO_STAGE_MIN_P
+                if two_stage:
+                    cm = core.permute(1, 0, 2).reshape(p, rl * rr)
                 outs = []
                 for a in range(ca):
-                    o = ops.env_step_right(Rn[0], G[a, 0], core)
-                    for b in range(1, cb):
-                        ops.env_step_right(Rn[b], G[a, b], core, out=o)
+                    o = None
+                    for b in range(cb):
+                        if two_stage:
+                            t = ((G[a, b] @ cm).reshape(-1, rl, rr) * Rn[b].unsqueeze(1)).sum(dim=2)
+                            o = t if o is None else o.add_(t)
+                        else:
+                            o = ops.env_step_right(Rn[b], G[a, b], core) if o is None else \
+                                ops.env_step_right(Rn[b], G[a, b], core, out=o)
                     outs.append(o)
                 d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
         return d.R[k]

@@ -170,7 +170,7 @@ class TensorNetwork:
 
     def _gram_matrix(self, lp, H, scale=None, ridge=0.0, out=None):
         """Dense (D,D) Gram matrix of a local problem, optionally scaled and ridged."""
-        if lp.single_term():
+        if lp.compressed_gram(self._hessian_symmetric(H)):
             ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
             return ops.gram_expand(ws, scale=scale, ridge=ridge, out=out)
         A = lp.dense_gram(H)
@@ -299,7 +299,7 @@ class TensorNetwork:
         ridged = m == 'ridge_exact' or m.startswith('ridge_cholesky')
         ridge = 2 * eps_ if ridged else 0.0
         b = lp.rhs(g)
-        if lp.single_term():
+        if lp.compressed_gram(self._hessian_symmetric(H)):
             # compressed symmetric Gram in the workspace, own Cholesky on it
             ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update

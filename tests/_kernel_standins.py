@@ -64,6 +64,10 @@ def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
     return _WS(A.contiguous(), (S, C, rl, X.shape[1], R.shape[1], int(bool(sym))))
 
 
+def gram_supported(S, C, rl, p, rr, sym=True):
+    return True
+
+
 def gram_scale(ws):
     s = ws.A.diagonal().abs().mean()
     return torch.where(s == 0, torch.ones_like(s), s)
@@ -120,7 +124,7 @@ def axpy(a, x, y, sign=1.0):
     return y.add_(sign * a * x)
 
 
-NAMES = ("env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
+NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
          "matvec solve_rhs chol_solve_gram qr dot axpy").split()
 
 

@@ -110,3 +110,35 @@ def test_conv_cholesky_sweep_golden(name):
 @pytest.mark.parametrize("name", G.names("conv_tt_"))
 def test_conv_lanczos_sweep_golden(name):
     check_lanczos_sweep(name, DEV)
+
+
+def check_many_patches(DEV, monkeypatch):
+    """Columns with many features take the contract-features-first route (library GEMMs); it must
+    give what the Khatri-Rao kernels give: forward, RHS and mat-vec of every node, conv bond 2."""
+    from tensornetworksfork_amd.tensor import engine
+    from tensornetworksfork_amd.tensor.layers import TensorConvolutionTrainLayer
+    torch.set_default_dtype(torch.float64)
+    results = []
+    for min_p in (16, 10 ** 6):
+        monkeypatch.setattr(engine, "TWO_STAGE_MIN_P", min_p)
+        torch.manual_seed(3)
+        layer = TensorConvolutionTrainLayer(3, 4, 20, 5, output_shape=3, convolution_bond=2).to(DEV)
+        tn = layer.tensor_network
+        g = torch.Generator().manual_seed(4)
+        x = (torch.rand(200, 20, 5, generator=g) - 0.5).to(DEV)
+        y = torch.nn.functional.one_hot(torch.randint(0, 4, (200,), generator=g), 4).to(torch.float64).to(DEV)
+        out = tn.forward(x, to_tensor=True)
+        loss, gr, H = _loss("xe").forward(out, y)
+        res = [out]
+        vg = torch.Generator().manual_seed(5)
+        for node in tn.train_nodes:
+            v = torch.randn(node.tensor.shape, generator=vg).to(DEV)
+            res += [tn.get_b(node, gr), tn.matvec(node, v, H)]
+        results.append(res)
+    for a, b in zip(*results):
+        assert G.rel_err(a, b) < 1e-12
+
+
+@gpu
+def test_conv_many_patches_two_stage(monkeypatch):
+    check_many_patches(DEV, monkeypatch)

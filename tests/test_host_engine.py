@@ -53,3 +53,7 @@ def test_other_topologies_host_logic(name, cpu_kernels):
     nets.check_local_problems(name, "cpu")
     nets.check_cholesky_sweep(name, "cpu")
     nets.check_lanczos_sweep(name, "cpu")
+
+
+def test_conv_many_patches_host_logic(cpu_kernels, monkeypatch):
+    conv.check_many_patches("cpu", monkeypatch)

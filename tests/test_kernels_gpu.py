@@ -198,3 +198,25 @@ def test_gram_feature_pair_classes():
     assert ((big - ref).abs().max() / ref.abs().max()).item() < 1e-13
     with pytest.raises(Exception):
         ops.gram(L, H, X, R, sym=True, pair_rep=[1] + list(range(1, p * (p + 1) // 2)))   # rep must not point forward
+
+
+@gpu
+def test_two_stage_products_match_kernels():
+    """Sites with many features contract the features first (library GEMM): same J v, J^T g and
+    mat-vec as the Khatri-Rao kernels."""
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor import engine
+    dev = _dev()
+    S, C, rl, p, rr = 1500, 3, 5, 20, 6
+    L, X, R = _rand((S, C, rl), 1).to(dev), _rand((S, p), 2).to(dev), _rand((S, rr), 3).to(dev)
+    Hs = _rand((S, C, C), 4).to(dev)
+    H = (Hs @ Hs.transpose(1, 2)).contiguous()
+    v, g = _rand((rl, p, rr), 5).to(dev), _rand((S, C), 6).to(dev)
+    lp = engine.LocalProblem(S, C, (rl, p, rr), v, lambda t: t, terms=[(L, X, R)])
+    assert p >= engine.TWO_STAGE_MIN_P
+    u_ref = ops.predict(ops.env_step_left(L, X, v), R)
+    assert ((lp.jv(v) - u_ref).norm() / u_ref.norm()).item() < 1e-13
+    b_ref = ops.rhs(L, X, R, g)
+    assert ((lp.rhs(g) - b_ref).norm() / b_ref.norm()).item() < 1e-13
+    mv_ref = ops.matvec(L, X, R, H, v)
+    assert ((lp.matvec_fn(H)(v) - mv_ref).norm() / mv_ref.norm()).item() < 1e-13
