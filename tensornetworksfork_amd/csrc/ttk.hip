@@ -1369,6 +1369,152 @@ __global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __
 // which is what fixes the gauge of the orthonormalised cores.
 // LDS: A (m x n, column-major, stride m+1) and tau; one column of reflector work per step.
 // ---------------------------------------------------------------------------------------
+// Register variant for m <= 256, n <= 32 (every core of the headline model): column c lives in
+// wave c % 4, slot c / 4, four rows per lane (row = lane + 64 e), so dot products and updates are
+// register arithmetic plus one wave reduction; a reflector crosses waves through a double-buffered
+// LDS vector (one barrier per column) and is kept in LDS for the Q formation, which needs no
+// barrier at all (columns are independent).  Same arithmetic and sign convention as qr_kernel.
+#define QRS_RPL 4
+#define QRS_CPW 8
+__global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict__ Ain, int m, int n,
+                                                        double* __restrict__ Q, double* __restrict__ Rout) {
+  __shared__ double V[32][256];      // reflector j: V[j][row], zero above j, one at j
+  __shared__ double tau[32];
+  const int k = min(m, n);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double a[QRS_CPW][QRS_RPL];
+#pragma unroll
+  for (int q = 0; q < QRS_CPW; ++q)
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) {
+      const int c = wave + 4 * q, r = lane + 64 * e;
+      const double v = Ain[(int64_t)min(r, m - 1) * n + min(c, n - 1)];
+      a[q][e] = (r < m && c < n) ? v : 0.0;
+    }
+  for (int j = 0; j < k; ++j) {
+    if (wave == (j & 3)) {
+      const int qj = j >> 2;
+      double col[QRS_RPL];
+#pragma unroll
+      for (int q = 0; q < QRS_CPW; ++q)
+        if (q == qj) {
+#pragma unroll
+          for (int e = 0; e < QRS_RPL; ++e) col[e] = a[q][e];
+        }
+      double part = 0.0, mine = 0.0;
+#pragma unroll
+      for (int e = 0; e < QRS_RPL; ++e) {
+        const int r = lane + 64 * e;
+        if (r > j) part += col[e] * col[e];
+        if (r == j) mine = col[e];
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        part += __shfl_xor(part, off, 64);
+        mine += __shfl_xor(mine, off, 64);   // only the lane that holds row j contributes
+      }
+      const double alpha = mine;
+      double t = 0.0, beta = alpha, scale = 0.0;
+      if (part != 0.0) {
+        const double nrm = sqrt(alpha * alpha + part);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        t = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+#pragma unroll
+      for (int e = 0; e < QRS_RPL; ++e) {
+        const int r = lane + 64 * e;
+        const double v = r > j ? col[e] * scale : (r == j ? 1.0 : 0.0);
+        V[j][r] = v;
+        col[e] = r > j ? v : (r == j ? beta : col[e]);
+      }
+#pragma unroll
+      for (int q = 0; q < QRS_CPW; ++q)
+        if (q == qj) {
+#pragma unroll
+          for (int e = 0; e < QRS_RPL; ++e) a[q][e] = col[e];
+        }
+      if (lane == 0) tau[j] = t;
+    }
+    __syncthreads();
+    double v[QRS_RPL];
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) v[e] = V[j][lane + 64 * e];
+    const double t = tau[j];
+    double acc[QRS_CPW];
+#pragma unroll
+    for (int q = 0; q < QRS_CPW; ++q) {
+      double d = 0.0;
+#pragma unroll
+      for (int e = 0; e < QRS_RPL; ++e) d += v[e] * a[q][e];
+      acc[q] = d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int q = 0; q < QRS_CPW; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < QRS_CPW; ++q) {
+      const int c = wave + 4 * q;
+      if (c > j && c < n) {
+        const double w = t * acc[q];
+#pragma unroll
+        for (int e = 0; e < QRS_RPL; ++e) a[q][e] -= v[e] * w;
+      }
+    }
+  }
+  // R = upper triangle (the diagonal holds beta)
+#pragma unroll
+  for (int q = 0; q < QRS_CPW; ++q)
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) {
+      const int c = wave + 4 * q, r = lane + 64 * e;
+      if (r < k && c < n) Rout[(int64_t)r * n + c] = (r <= c) ? a[q][e] : 0.0;
+    }
+  __syncthreads();   // every reflector is in V
+  // Q = H_1 ... H_k I[:, :k], own columns, last reflector first; H_j leaves unit columns left of j alone
+#pragma unroll
+  for (int q = 0; q < QRS_CPW; ++q)
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) a[q][e] = (lane + 64 * e == wave + 4 * q) ? 1.0 : 0.0;
+  for (int j = k - 1; j >= 0; --j) {
+    double v[QRS_RPL];
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) v[e] = V[j][lane + 64 * e];
+    const double t = tau[j];
+    double acc[QRS_CPW];
+#pragma unroll
+    for (int q = 0; q < QRS_CPW; ++q) {
+      double d = 0.0;
+#pragma unroll
+      for (int e = 0; e < QRS_RPL; ++e) d += v[e] * a[q][e];
+      acc[q] = d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int q = 0; q < QRS_CPW; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < QRS_CPW; ++q) {
+      const int c = wave + 4 * q;
+      if (c >= j && c < k) {
+        const double w = t * acc[q];
+#pragma unroll
+        for (int e = 0; e < QRS_RPL; ++e) a[q][e] -= v[e] * w;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QRS_CPW; ++q)
+#pragma unroll
+    for (int e = 0; e < QRS_RPL; ++e) {
+      const int c = wave + 4 * q, r = lane + 64 * e;
+      if (r < m && c < k) Q[(int64_t)r * k + c] = a[q][e];
+    }
+}
+
 __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain, int m, int n, double* __restrict__ Q,
                                                   double* __restrict__ Rout) {
   extern __shared__ double smem[];
@@ -1408,15 +1554,33 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
     }
     __syncthreads();
     const double t = tau[j];
-    int c = j + 1 + ((wave - (j + 1)) & 3);   // first own column right of j
-    for (; c < n; c += 4) {
-      double* ac = A + (size_t)c * ldm;
-      double acc = 0.0;
-      for (int r = j + 1 + lane; r < m; r += 64) acc += vj[r] * ac[r];
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      const double w = t * (acc + ac[j]);
-      for (int r = j + 1 + lane; r < m; r += 64) ac[r] -= vj[r] * w;
-      if (lane == 0) ac[j] -= w;
+    // own columns right of j, eight at a time: their dot products are reduced together so that the
+    // shuffle latencies overlap instead of adding up column after column
+    for (int c0 = j + 1 + ((wave - (j + 1)) & 3); c0 < n; c0 += 32) {
+      double acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = min(c0 + 4 * q, n - 1);
+        const double* ac = A + (size_t)c * ldm;
+        double a = 0.0;
+        for (int r = j + 1 + lane; r < m; r += 64) a += vj[r] * ac[r];
+        acc[q] = a;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 4 * q;
+        if (c < n) {
+          double* ac = A + (size_t)c * ldm;
+          const double w = t * (acc[q] + ac[j]);
+          for (int r = j + 1 + lane; r < m; r += 64) ac[r] -= vj[r] * w;
+          if (lane == 0) ac[j] -= w;
+        }
+      }
     }
   }
   __syncthreads();
@@ -1428,17 +1592,44 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   // Q = H_1 ... H_k I[:, :k] (dorg2r).  Column c of the identity is touched by H_j only for
   // j <= c, and the columns are independent: each wave runs its own columns through their
   // reflectors from the last one backwards, no barrier.
-  for (int c = wave; c < k; c += 4) {
-    double* qc = Qw + (size_t)c * ldm;
-    for (int r = lane; r < m; r += 64) qc[r] = (r == c) ? 1.0 : 0.0;
-    for (int j = c; j >= 0; --j) {
+  for (int c0 = wave; c0 < k; c0 += 32) {   // eight own columns together (interleaved reductions)
+    int jtop = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + 4 * q;
+      if (c < k) {
+        double* qc = Qw + (size_t)c * ldm;
+        for (int r = lane; r < m; r += 64) qc[r] = (r == c) ? 1.0 : 0.0;
+        jtop = c;
+      }
+    }
+    for (int j = jtop; j >= 0; --j) {
       const double* vj = A + (size_t)j * ldm;
-      double acc = 0.0;
-      for (int r = j + 1 + lane; r < m; r += 64) acc += vj[r] * qc[r];
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      const double w = tau[j] * (acc + qc[j]);
-      for (int r = j + 1 + lane; r < m; r += 64) qc[r] -= vj[r] * w;
-      if (lane == 0) qc[j] -= w;
+      const double t = tau[j];
+      double acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = min(c0 + 4 * q, k - 1);
+        const double* qc = Qw + (size_t)c * ldm;
+        double a = 0.0;
+        for (int r = j + 1 + lane; r < m; r += 64) a += vj[r] * qc[r];
+        acc[q] = a;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 4 * q;
+        if (c < k && c >= j) {   // H_j leaves the unit columns left of j alone
+          double* qc = Qw + (size_t)c * ldm;
+          const double w = t * (acc[q] + qc[j]);
+          for (int r = j + 1 + lane; r < m; r += 64) qc[r] -= vj[r] * w;
+          if (lane == 0) qc[j] -= w;
+        }
+      }
     }
   }
   __syncthreads();
@@ -1755,6 +1946,10 @@ int64_t ttk_qr_lds_bytes(int m, int n) {
 
 int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream) {
   if (!A || !Q || !R || m < 1 || n < 1) return TTK_EINVAL;
+  if (m <= 64 * QRS_RPL && n <= 4 * QRS_CPW) {
+    hipLaunchKernelGGL(qr_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, m, n, Q, R);
+    return ttk_launch_status();
+  }
   const int64_t lds = ttk_qr_lds_bytes(m, n);
   if (lds > 150 * 1024) return TTK_EINVAL;
   if (lds > 64 * 1024 &&
