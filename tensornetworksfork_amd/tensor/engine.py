@@ -41,6 +41,8 @@ class _Data:
         self.L = [None] * N
         self.R = [None] * N
         self.G = [None] * N
+        self.hot = 0               # column that changed last
+        self.pairs_done = False
         self.seenA = [None] * N    # (tensor, version) of A_k / F_k when the caches were last valid
         self.seenF = [None] * N
 
@@ -62,32 +64,45 @@ PAIR_CLASS_TOL = 16.0      # products that agree to this many ulps (of the colum
 def pair_classes(X):
     """Classes of feature pairs (i<=j, upper-triangle row-major) whose products X_i X_j coincide on
     every sample, as the list rep[b] = first pair of b's class; None when all pairs differ or p is
-    above the limit.  A polynomial basis X_i = x^i gives the p(p+1)/2 pairs 2p-1 classes (i+j).
+    above the limit.  A polynomial basis X_i = x^i gives the p(p+1)/2 pairs 2p-1 classes (i+j)."""
+    return pair_classes_many([X])[0]
+
+
+def pair_classes_many(Xs):
+    """pair_classes for several feature matrices of one shape at once (two host round trips in all).
     Candidates come from a strided subset of the samples and are then checked on all of them."""
-    S, p = X.shape
+    S, p = Xs[0].shape
     if p < 2 or p > PAIR_CLASS_MAX_P or S == 0:
-        return None
-    iu = torch.triu_indices(p, p, device=X.device)
-    Xt = X.T.contiguous()                                      # reductions run along contiguous rows
-    XX = Xt[iu[0]] * Xt[iu[1]]                                 # (NX, S), same pair order as the kernels
-    NX = XX.shape[0]
+        return [None] * len(Xs)
+    dev = Xs[0].device
+    iu = torch.triu_indices(p, p, device=dev)
+    Xt = torch.stack([X.T for X in Xs])                        # (n, p, S): reductions run along contiguous rows
+    XX = Xt[:, iu[0]] * Xt[:, iu[1]]                           # (n, NX, S), same pair order as the kernels
+    n, NX = XX.shape[0], XX.shape[1]
     tol = PAIR_CLASS_TOL * torch.finfo(XX.dtype).eps
-    sub = XX[:, ::max(1, S // 1024)][:, :2048]
-    big = sub.abs().amax(dim=1)
-    diff = (sub.unsqueeze(1) - sub.unsqueeze(0)).abs().amax(dim=2)
-    same = (diff <= tol * torch.maximum(big.unsqueeze(0), big.unsqueeze(1))).cpu()
-    rep = list(range(NX))
-    for b in range(NX):
-        for a in range(b):
-            if rep[a] == a and bool(same[a, b]):
-                rep[b] = a
-                break
-    if all(rep[b] == b for b in range(NX)):
-        return None
-    rt = torch.tensor(rep, device=X.device)
-    ok = ((XX - XX[rt]).abs().amax(dim=1) <= tol * XX.abs().amax(dim=1)).cpu()
-    rep = [rep[b] if bool(ok[b]) else b for b in range(NX)]
-    return None if all(rep[b] == b for b in range(NX)) else rep
+    sub = XX[:, :, ::max(1, S // 1024)][:, :, :2048]
+    big = sub.abs().amax(dim=2)
+    diff = (sub.unsqueeze(2) - sub.unsqueeze(1)).abs().amax(dim=3)
+    same = (diff <= tol * torch.maximum(big.unsqueeze(1), big.unsqueeze(2))).cpu()
+    reps = []
+    for i in range(n):
+        rep = list(range(NX))
+        for b in range(NX):
+            for a in range(b):
+                if rep[a] == a and bool(same[i, a, b]):
+                    rep[b] = a
+                    break
+        reps.append(rep)
+    if all(rep == list(range(NX)) for rep in reps):
+        return [None] * n
+    rt = torch.tensor(reps, device=dev)                         # (n, NX)
+    ref = torch.gather(XX, 1, rt.unsqueeze(2).expand(n, NX, S))
+    ok = ((XX - ref).abs().amax(dim=2) <= tol * XX.abs().amax(dim=2)).cpu()
+    out = []
+    for i in range(n):
+        rep = [reps[i][b] if bool(ok[i, b]) else b for b in range(NX)]
+        out.append(None if all(rep[b] == b for b in range(NX)) else rep)
+    return out
 
 
 def _xt_times(X, W, chunk=1024):
@@ -274,14 +289,30 @@ class EngineBase:
         self._gram_ws[key] = ws
         return ws
 
+    @staticmethod
+    def _pair_key(X):
+        return (X.data_ptr(), tuple(X.shape), X._version)
+
     def pair_rep(self, X):
         """Feature-pair classes of a feature matrix, detected once per tensor (and version)."""
-        key = (X.data_ptr(), tuple(X.shape), X._version)
+        key = self._pair_key(X)
         if key not in self._pairs:
             if len(self._pairs) > 256:
                 self._pairs.clear()
             self._pairs[key] = pair_classes(X)
         return self._pairs[key]
+
+    def prefetch_pairs(self, Xs):
+        """Detect the classes of several feature matrices in one go (all sites of a data set when the
+        first Gram is asked for), so that a sweep does not stop at every new site for it."""
+        todo = {}
+        for X in Xs:
+            if X.ndim == 2 and 2 <= X.shape[1] <= PAIR_CLASS_MAX_P and self._pair_key(X) not in self._pairs:
+                todo.setdefault(tuple(X.shape), {})[self._pair_key(X)] = X
+        for group in todo.values():
+            keys = list(group)
+            for key, rep in zip(keys, pair_classes_many([group[k] for k in keys])):
+                self._pairs[key] = rep
 
     def dense_buffer(self, D, device):
         buf = self._abuf.get(D)
@@ -520,6 +551,7 @@ class ChainEngine(EngineBase):
                 d.L[k] = None
             for k in range(0, last):
                 d.R[k] = None
+            d.hot = last
 
     # ------------------------------------------------------------------ features and environments
     def feats(self, d, k):
@@ -618,7 +650,9 @@ class ChainEngine(EngineBase):
             vr = N - 1
             while vr - 1 >= 0 and d.R[vr - 1] is not None:
                 vr -= 1
-            k = min(range(N), key=lambda j: max(0, j - vl) + max(0, vr - j))
+            # among equally cheap cuts take the one next to the column that changed last: a sweep moves on
+            # from there, so the environments built up to it stay valid for the following predictions
+            k = min(range(N), key=lambda j: (max(0, j - vl) + max(0, vr - j), abs(j - d.hot)))
         Lk1 = self.left_step(d, k, self.canonA(k))
         R = self.right(d, k)
         y = ops.predict(Lk1[0], R[0])
@@ -636,6 +670,9 @@ class ChainEngine(EngineBase):
         col = self.cols[k]
         back = lambda t, node=node: self.from_canon(node, t)   # noqa: E731
         if kind == "A":
+            if not d.pairs_done:      # plain columns: G[0, 0] is the input itself
+                d.pairs_done = True
+                self.prefetch_pairs([self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"])
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
             return LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
         # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (plain batched library GEMMs)

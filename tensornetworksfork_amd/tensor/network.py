@@ -35,6 +35,7 @@ class TensorNetwork:
         self.nodes, self.node_indices = self._discover_nodes()
         self._current = None
         self._shard = None
+        self._pending = None
         self._engine = self._make_engine()
 
     def _make_engine(self):
@@ -311,11 +312,10 @@ class TensorNetwork:
                 x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
             else:
                 x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
-                bad = int(info.item())
-                if bad != 0:
-                    raise torch.linalg.LinAlgError(
-                        "linalg.cholesky: The factorization could not be completed because the input is not "
-                        f"positive-definite (the leading minor of order {bad} is not positive-definite).")
+                # the pivot check needs the host; it is settled after the gauge move has been queued
+                # (see _settle), so that nothing waits for the factorisation to drain first
+                self._pending = (info, [(n, n.tensor, list(n.dim_labels), list(n.left_labels), list(n.right_labels))
+                                        for n in dict.fromkeys(list(self.main_nodes) + [node])])
         else:
             # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
             A_f = lp.dense_gram(H)
@@ -330,7 +330,23 @@ class TensorNetwork:
             rhs = ops.solve_rhs(b, core if ridged else None, scale, ridge).reshape(-1)
             x = torch.linalg.solve(A_f, rhs) if m in ('exact', 'ridge_exact') else _cholesky_solve(A_f, rhs)
         node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
-        return None if total is None else total.item()
+        return total
+
+    def _settle(self):
+        """Host-side check of the last Cholesky: on a non-positive pivot the nodes are put back as they
+        were before the update (the reference raises inside solve_system, before any update) and
+        torch.linalg.LinAlgError is raised."""
+        pending, self._pending = self._pending, None
+        if pending is None:
+            return
+        info, snapshot = pending
+        bad = int(info.item())
+        if bad != 0:
+            for n, t, labels, left, right in snapshot:
+                n.tensor, n.dim_labels, n.left_labels, n.right_labels = t, labels, left, right
+            raise torch.linalg.LinAlgError(
+                "linalg.cholesky: The factorization could not be completed because the input is not "
+                f"positive-definite (the leading minor of order {bad} is not positive-definite).")
 
     def _batch_mean_loss(self, d, loss, batch_size):
         """Mean over the reference's mini-batches of per-batch mean losses (device scalar);
@@ -374,6 +390,7 @@ class TensorNetwork:
             if k_ not in _LEGACY_KWARGS:
                 raise TypeError(f"accumulating_swipe() got an unexpected keyword argument '{k_}'")
         self._require_chain()
+        self._pending = None
         d = self._data_for(x, shard=self._shard)
         self._current = d
         device = d.xs[0].device
@@ -411,14 +428,17 @@ class TensorNetwork:
                     else:
                         loss = self._site_update(d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step,
                                                  min_norm, max_norm, want_loss)
+                    if orthonormalize:
+                        (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
+                    self._settle()
                 except torch.linalg.LinAlgError:
                     if verbose and verbose > 0:
                         print(f"Singular system for node {node.name}")
                     return False
+                if isinstance(loss, torch.Tensor):
+                    loss = loss.item()
                 if verbose and verbose > 1:
                     print(f"NS: {NS}, {'Left' if which == 'fwd' else 'Right'} loss ({node.name}):", loss, f" (eps: {eps_})")
-                if orthonormalize:
-                    (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
                 if loss_callback is not None:
                     loss_callback(NS, node, loss)
                 if convergence_criterion is not None and convergence_criterion():

@@ -193,5 +193,9 @@ def test_legacy_kwargs_and_errors():
     with pytest.raises(TypeError):
         tn.accumulating_swipe(x, y, SquareBregFunction(), bogus=1)
     # singular system without ridge -> False, like the reference's LinAlgError branch
+    before = [(n.tensor.clone(), list(n.dim_labels)) for n in tn.main_nodes]
+    assert tn.accumulating_swipe(x[:2], y[:2], SquareBregFunction(), method="cholesky", orthonormalize=True) is False
+    for n, (t, labels) in zip(tn.main_nodes, before):      # the failed update (and its gauge move) is undone
+        assert list(n.dim_labels) == labels and torch.equal(n.tensor, t)
     assert tn.accumulating_swipe(x[:2], y[:2], SquareBregFunction(), method="cholesky") is False
     assert tn.accumulating_swipe(x, y, SquareBregFunction(), method="ridge_cholesky", eps=1.0, timeout=0.0) is False
