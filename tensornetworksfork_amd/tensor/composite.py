@@ -349,6 +349,10 @@ class SumEngine(EngineBase):
         i, eng = self._engine_of(node)
         return eng.local(d.parts[i], node)
 
+    def prefetch(self, d, node):
+        i, eng = self._engine_of(node)
+        eng.prefetch(d.parts[i], node)
+
     def output_at(self, d, node, lp, core=None, rows=None):
         i, eng = self._engine_of(node)
         y = eng.output_at(d.parts[i], node, lp, core, rows)

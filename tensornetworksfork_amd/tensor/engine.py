@@ -278,6 +278,9 @@ class EngineBase:
         node); `rows` names the sample range a sliced problem covers."""
         return lp.jv(lp.core if core is None else core)
 
+    def prefetch(self, d, node):
+        """Bring up to date whatever cached state the local problem of `node` will read."""
+
     # -- Gram + solve workspaces
     def gram_ws(self, lp, H, sym):
         L, X, R = lp.terms[0]
@@ -632,6 +635,13 @@ class ChainEngine(EngineBase):
                     outs.append(o)
                 d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
         return d.R[k]
+
+    def prefetch(self, d, node):
+        self.sync(d)
+        k, _ = self.column_of(node)
+        self.left(d, k)
+        self.right(d, k)
+        self.feats(d, k)
 
     def refresh(self, d):
         """Bring every cached environment up to date (the reference's recompute_all_stacks)."""

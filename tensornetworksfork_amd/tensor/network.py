@@ -314,6 +314,12 @@ class TensorNetwork:
                 x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
                 # the pivot check needs the host; it is settled after the gauge move has been queued
                 # (see _settle), so that nothing waits for the factorisation to drain first
+                if info.is_cuda:   # copied to pinned memory now, so that reading it does not wait for later kernels
+                    host = torch.empty((), dtype=info.dtype, pin_memory=True)
+                    host.copy_(info, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    info = (host, ready)
                 self._pending = (info, [(n, n.tensor, list(n.dim_labels), list(n.left_labels), list(n.right_labels))
                                         for n in dict.fromkeys(list(self.main_nodes) + [node])])
         else:
@@ -340,6 +346,9 @@ class TensorNetwork:
         if pending is None:
             return
         info, snapshot = pending
+        if isinstance(info, tuple):
+            info[1].synchronize()
+            info = info[0]
         bad = int(info.item())
         if bad != 0:
             for n, t, labels, left, right in snapshot:
@@ -435,6 +444,12 @@ class TensorNetwork:
                     if verbose and verbose > 0:
                         print(f"Singular system for node {node.name}")
                     return False
+                if i + 1 < len(order) and method != 'gradient':
+                    # queue the next node's environments before the callbacks take the host (their
+                    # results are cached by node identity, so a callback that changes nodes is safe)
+                    nxt = order[i + 1]
+                    if not (nxt in self.node_indices and self.node_indices[nxt] == self.node_indices.get(last[other])):
+                        self._engine.prefetch(d, nxt)
                 if isinstance(loss, torch.Tensor):
                     loss = loss.item()
                 if verbose and verbose > 1:
