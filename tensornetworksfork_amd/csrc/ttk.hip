@@ -909,6 +909,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ au
   __shared__ double S1[CHB][CHB + 1];
   __shared__ double rsd[CHB];
   __shared__ double piv[16];
+  __shared__ double colb[2][CHB];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   const int i = j + blockIdx.x;
@@ -1003,14 +1004,19 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ au
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           if (lane == 0) piv[c] = d;
+          // The column goes to LDS for the bulk of the updates (uniform-address reads: one
+          // instruction per value instead of two scalar lane reads); a wave's LDS accesses execute
+          // in order, the empty asm only keeps the compiler from moving the reads above the write.
+          colb[c & 1][lane] = a[c];
+          asm volatile("" ::: "memory");
           const double t = -a[c] * rc;
-          if (c + 1 < 16) {   // next pivot first: its reciprocal chain runs under the other updates
+          if (c + 1 < 16) {   // next pivot first, by lane reads: its reciprocal chain runs under the other updates
             a[c + 1] = fma(t, readlane_f64(a[c], c0 + c + 1), a[c + 1]);
             d = readlane_f64(a[c + 1], c0 + c + 1);
             rc = rcp_f64(d);
           }
 #pragma unroll
-          for (int cc = c + 2; cc < 16; ++cc) a[cc] = fma(t, readlane_f64(a[c], c0 + cc), a[cc]);
+          for (int cc = c + 2; cc < 16; ++cc) a[cc] = fma(t, colb[c & 1][c0 + cc], a[cc]);
         }
         const double dv = piv[lane & 15];
         double rsv, sqv;
