@@ -1124,20 +1124,34 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict_
 }
 
 // Trailing update  C[r][c] -= sum_{kk < K} P[r][kk] P[c][kk]  with P the K panel columns that
-// start at column pc0, on the lower 128x128 tiles of the region that starts at row/column o0
-// (a multiple of 64).  4 waves as 2x2, each 64x64 (16 accumulators that start as the C tile,
-// the row operand is negated, so the result is stored without a read-modify-write tail).
+// start at column pc0, on the lower TS x TS tiles of the region that starts at row/column o0
+// (a multiple of 64).  4 waves as 2x2, each a (TS/2)^2 wave tile of 16x16 MFMA tiles; the
+// accumulators start at zero and absorb the C tile underneath the first k-chunks, the row
+// operand is negated, so the result is stored without a read-modify-write tail.
 // The panel rows of the tile are staged k-major through LDS in chunks of 16 columns, the next
 // chunk travelling in registers while the current one is multiplied.
 // Tile order: 4x4 super-tiles; blocks b, b+8, b+16, ... (the blocks that share an XCD under
-// round-robin dispatch) walk the 16 tiles of one super-tile, so its 2 x 4 x 128 panel rows
-// (1 MiB) are fetched into that XCD's L2 once per super-tile.  Placement affects speed only.
+// round-robin dispatch) walk the 16 tiles of one super-tile, so its 2 x 4 x TS panel rows
+// are fetched into that XCD's L2 once per super-tile.  Placement affects speed only.
+// Measured at order 6144, K = 128: 64x64 tiles (4 workgroups per CU) beat 128x128 tiles
+// (2 per CU) at every trailing size - 109 vs 130 us for 6016 rows, 11 vs 26 us for 1024 -
+// because work arrives in finer units (a 128x128 round of 512 slots is 43 us long) and
+// more co-resident waves cover the staging barriers.
 #define SYK 16
 #define SYS 4
-__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ aug, int ld, int pc0, int K, int o0,
-                                                            int nrows, int ncols, int nst_rows) {
-  __shared__ double As[SYK][129];
-  __shared__ double Bs[SYK][129];
+#define SYRK_SMALL_TILES (1 << 30)   // measured: the 64x64 tiles win at every trailing size up to 6144
+// NT = MFMA tiles per wave and dimension: 4 -> 128x128 workgroup tiles, 2 -> 64x64 (finer load
+// balance and a shorter single-tile latency for small trailing matrices).
+template <int NT>
+__global__ __launch_bounds__(256, (NT == 4 ? 2 : 4)) void chol_syrk_kernel(double* __restrict__ aug, int ld, int pc0,
+                                                                             int K, int o0, int nrows, int ncols,
+                                                                             int nst_rows) {
+  constexpr int TS = 32 * NT;       // workgroup tile
+  constexpr int WT = 16 * NT;       // wave tile
+  constexpr int EPT = NT * SYK / 8; // staged doubles per thread, row operand and column operand each
+  constexpr int TPR = SYK / EPT;    // threads per staged row
+  __shared__ double As[SYK][TS + 1];
+  __shared__ double Bs[SYK][TS + 1];
   const int b = blockIdx.x;
   int ti, tk;
   if (nst_rows <= 0) {   // one tile column: blockIdx.x is the tile row
@@ -1155,101 +1169,101 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
     ti = si * SYS + (within & (SYS - 1));
     tk = rem * SYS + (within / SYS);
   }
-  const int r0 = o0 + ti * 128, c0 = o0 + tk * 128;
+  const int r0 = o0 + ti * TS, c0 = o0 + tk * TS;
   if (ti < tk || r0 >= nrows || c0 >= ncols) return;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  const int srow = tid >> 1, sk = (tid & 1) * 8;
+  const int srow = tid / TPR, sk = (tid % TPR) * EPT;
   // rows past the end are clamped, not predicated (a load under a per-element branch is
   // waited for one by one); what they feed is never stored.
   const double* Ap = aug + (int64_t)min(r0 + srow, nrows - 1) * ld + pc0 + sk;
   const double* Bp = aug + (int64_t)min(c0 + srow, ncols - 1) * ld + pc0 + sk;
-  double pa[8], pb[8];
+  double pa[EPT], pb[EPT];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     pa[e] = Ap[e];
     pb[e] = Bp[e];
   }
-  // The accumulators start at zero; the C tile is fetched in four quarters (one 16-row group of
-  // every wave per k-chunk) underneath the products of the first four chunks and added in, so
+  // The accumulators start at zero; the C tile is fetched in NT parts (one 16-row group of
+  // every wave per k-chunk) underneath the products of the first chunks and added in, so
   // that its latency is not paid in front of the loop.
-  d4 acc[4][4];
+  d4 acc[NT][NT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
-  const int ccol0 = c0 + wc * 64 + li;
+    for (int v = 0; v < NT; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+  const int ccol0 = c0 + wc * WT + li;
   int q = 0;
   for (int kc = 0; kc < K; kc += SYK, ++q) {
-    double ct[4][4];
-    if (q < 4) {
+    double ct[NT][4];
+    if (q < NT) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const double* crow = aug + (int64_t)min(r0 + wr * 64 + q * 16 + kq + 4 * t, nrows - 1) * ld;
+        const double* crow = aug + (int64_t)min(r0 + wr * WT + q * 16 + kq + 4 * t, nrows - 1) * ld;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) ct[v][t] = crow[min(ccol0 + v * 16, ncols - 1)];
+        for (int v = 0; v < NT; ++v) ct[v][t] = crow[min(ccol0 + v * 16, ncols - 1)];
       }
     }
     if (kc) __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       As[sk + e][srow] = -pa[e];   // negated here, not at the load: nothing may wait on the prefetch early
       Bs[sk + e][srow] = pb[e];
     }
     __syncthreads();
     if (kc + SYK < K) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         pa[e] = Ap[kc + SYK + e];
         pb[e] = Bp[kc + SYK + e];
       }
     }
 #pragma unroll
     for (int k0 = 0; k0 < SYK; k0 += 4) {
-      double af[4], bf[4];
+      double af[NT], bf[NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        af[u] = As[k0 + kq][wr * 64 + u * 16 + li];
-        bf[u] = Bs[k0 + kq][wc * 64 + u * 16 + li];
+      for (int u = 0; u < NT; ++u) {
+        af[u] = As[k0 + kq][wr * WT + u * 16 + li];
+        bf[u] = Bs[k0 + kq][wc * WT + u * 16 + li];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = MFMA_F64(af[u], bf[v], acc[u][v]);
+        for (int v = 0; v < NT; ++v) acc[u][v] = MFMA_F64(af[u], bf[v], acc[u][v]);
     }
-    if (q < 4) {
+    if (q < NT) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < NT; ++u)
         if (u == q) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
+          for (int v = 0; v < NT; ++v)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[u][v][t] += ct[v][t];
         }
     }
   }
-  for (; q < 4; ++q) {   // K < 64: quarters the loop did not reach
+  for (; q < NT; ++q) {   // short K: parts the loop did not reach
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NT; ++u)
       if (u == q) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const double* crow = aug + (int64_t)min(r0 + wr * 64 + q * 16 + kq + 4 * t, nrows - 1) * ld;
+          const double* crow = aug + (int64_t)min(r0 + wr * WT + q * 16 + kq + 4 * t, nrows - 1) * ld;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) acc[u][v][t] += crow[min(ccol0 + v * 16, ncols - 1)];
+          for (int v = 0; v < NT; ++v) acc[u][v][t] += crow[min(ccol0 + v * 16, ncols - 1)];
         }
       }
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int row = r0 + wr * 64 + u * 16 + kq + 4 * t;
+      const int row = r0 + wr * WT + u * 16 + kq + 4 * t;
       if (row < nrows) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int col = c0 + wc * 64 + v * 16 + li;
+        for (int v = 0; v < NT; ++v) {
+          const int col = c0 + wc * WT + v * 16 + li;
           if (col < ncols) aug[(int64_t)row * ld + col] = acc[u][v][t];
         }
       }
@@ -1852,17 +1866,29 @@ int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_lef
   return ttk_launch_status();
 }
 
+static int g_group4_min = 2048;   // trailing order above which panels are applied four at a time
+static int g_syrk_tile = 0;   // 0: chosen from the trailing size
 static void chol_syrk_launch(hipStream_t st, double* aug, int ld, int pc0, int K, int o0, int nrows, int ncols) {
   if (o0 >= ncols || o0 >= nrows) return;
-  const int trows = (nrows - o0 + 127) / 128;
-  if (ncols - o0 <= 128) {
-    hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)trows), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, 0);
+  // 64x64 tiles while the 128x128 ones would leave compute units idle or half a round of slots empty
+  const int t128 = (nrows - o0 + 127) / 128;
+  const int64_t n128 = (int64_t)t128 * (t128 + 1) / 2;
+  const int TS = g_syrk_tile ? g_syrk_tile : (n128 < SYRK_SMALL_TILES ? 64 : 128);
+  const int trows = (nrows - o0 + TS - 1) / TS;
+  if (ncols - o0 <= TS) {
+    if (TS == 64)
+      hipLaunchKernelGGL(chol_syrk_kernel<2>, dim3((unsigned)trows), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, 0);
+    else
+      hipLaunchKernelGGL(chol_syrk_kernel<4>, dim3((unsigned)trows), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, 0);
     return;
   }
   const int nst_rows = (trows + SYS - 1) / SYS;
   const int nst = nst_rows * (nst_rows + 1) / 2;
   const unsigned grid = (unsigned)((nst + 7) / 8) * 8 * SYS * SYS;
-  hipLaunchKernelGGL(chol_syrk_kernel, dim3(grid), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, nst_rows);
+  if (TS == 64)
+    hipLaunchKernelGGL(chol_syrk_kernel<2>, dim3(grid), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, nst_rows);
+  else
+    hipLaunchKernelGGL(chol_syrk_kernel<4>, dim3(grid), dim3(256), 0, st, aug, ld, pc0, K, o0, nrows, ncols, nst_rows);
 }
 
 #ifdef TTK_DEBUG_HOOKS
@@ -1870,6 +1896,8 @@ int ttk_debug_syrk(double* aug, int ld, int pc0, int K, int o0, int nrows, int n
   chol_syrk_launch((hipStream_t)stream, aug, ld, pc0, K, o0, nrows, ncols);
   return 0;
 }
+int ttk_debug_syrk_tile(int ts) { g_syrk_tile = ts; return 0; }
+int ttk_debug_group(int g) { g_group4_min = g; return 0; }
 int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
 #endif
 
@@ -1886,13 +1914,28 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   // One stream.  (A look-ahead that factorises the next pair of panels on a second,
   // high-priority stream beside the trailing update was measured and gained nothing: the
   // panel workgroups queue behind resident trailing-update workgroups for CU space.)
+  // Panels are applied to the trailing matrix in pairs (K = 128).  While the trailing matrix is large,
+  // two pairs are combined: the first pair goes onto the next pair's two block columns only (one narrow
+  // launch), then all four panels (K = 256) onto everything right of them, which sweeps the large
+  // trailing matrix half as often; for small trailing matrices the extra launch costs more than it saves.
+  int base = -1;   // first panel of an open group of four
   for (int j = 0; j < nb; ++j) {
     // odd panels first absorb the previous panel's update of their own block column
     hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info);
-    // panels j-1 and j together (K = 128) onto everything right of column j.  (Four panels per
-    // trailing update, K = 256, with a narrow K = 128 update in between, was measured slower:
-    // the narrow update costs a full tile latency.)
-    if ((j & 1) && j + 1 < nb) chol_syrk_launch(st, aug, ld, (j - 1) * CHB, 2 * CHB, (j + 1) * CHB, nrows, ncols);
+    if (j + 1 >= nb) break;
+    if (base < 0) {
+      if (j & 1) {
+        if ((nb - (j + 1)) * CHB > g_group4_min && j + 2 < nb) {
+          chol_syrk_launch(st, aug, ld, (j - 1) * CHB, 2 * CHB, (j + 1) * CHB, nrows, min(ncols, (j + 3) * CHB));
+          base = j - 1;
+        } else {
+          chol_syrk_launch(st, aug, ld, (j - 1) * CHB, 2 * CHB, (j + 1) * CHB, nrows, ncols);
+        }
+      }
+    } else if (j - base == 3) {
+      chol_syrk_launch(st, aug, ld, base * CHB, 4 * CHB, (j + 1) * CHB, nrows, ncols);
+      base = -1;
+    }
   }
   hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, invL);
   int rc = ttk_launch_status();

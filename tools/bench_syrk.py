@@ -3,6 +3,7 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tensornetworksfork_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libttk_dbg.so')
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 nb = 96
@@ -13,8 +14,10 @@ st = torch.cuda.current_stream().cuda_stream
 vp = ctypes.c_void_p
 lib.ttk_debug_syrk.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for K in (128, 256):
-    for o0 in (K, 2048, 4096, 5120, 5888):
+for TS in (128, 64):
+  lib.ttk_debug_syrk_tile(TS)
+  for K in (128,):
+    for o0 in (K, 1024, 2048, 3072, 4096, 5120, 5888):
         for _ in range(2):
             lib.ttk_debug_syrk(aug.data_ptr(), ld, 0, K, o0, nrows, ld, st)
         torch.cuda.synchronize()
@@ -27,4 +30,4 @@ for K in (128, 256):
         ms = e0.elapsed_time(e1) / reps
         n = ld - o0
         flops = (n * (n + 128) / 2 + 64 * n) * K * 2     # lower tiles incl. diagonal tiles + the extra block row
-        print(f"K={K} o0={o0} n={n} {ms * 1e3:.1f} us  {flops / ms * 1e-9:.1f} TF/s", flush=True)
+        print(f"TS={TS} K={K} o0={o0} n={n} {ms * 1e3:.1f} us  {flops / ms * 1e-9:.1f} TF/s", flush=True)
