@@ -3,7 +3,7 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tensornetworksfork_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libttk_dbg.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get('TTK_DBG', 'libttk_dbg.so'))
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 nb = 96
@@ -14,7 +14,7 @@ st = torch.cuda.current_stream().cuda_stream
 vp = ctypes.c_void_p
 lib.ttk_debug_syrk.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for TS in (128, 64):
+for TS in (64,):
   lib.ttk_debug_syrk_tile(TS)
   for K in (128,):
     for o0 in (K, 1024, 2048, 3072, 4096, 5120, 5888):
