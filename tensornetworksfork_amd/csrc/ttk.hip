@@ -32,7 +32,7 @@ static inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m 
 // lanes of a k-group read 16 consecutive doubles.
 // ---------------------------------------------------------------------------------------
 template <bool LEFT>
-__global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict__ E, const double* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void env_step_kernel(const double* __restrict__ E, const double* __restrict__ X,
                                                         const double* __restrict__ core, double* __restrict__ out,
                                                         int64_t M, int C, int e, int p, int n, int KC, int accumulate) {
   extern __shared__ double smem[];
@@ -137,8 +137,247 @@ __global__ __launch_bounds__(256) void env_step_kernel(const double* __restrict_
   }
 }
 
+// Environment step with the whole core resident in LDS (K * npad doubles), for the common case of
+// a small core and very many rows.  A workgroup stages the core once, then its four waves walk
+// over 16-row tiles (grid stride): the E and X rows of a tile are fetched into registers (the
+// next tile's while the current one is multiplied), transposed into a per-wave LDS tile, and the
+// left operand E[row,ei] * X[row,pi] is formed per lane from a (ei, pi) offset table.
+// mode 0: out[row, :] (+)= result;  mode 1: out[row] (+)= <result row, Rdot[row / C, :]> [* Hmul[row]]  (J v).
+//
+// Core rows in LDS are column-permuted: element (k, j) sits at column j ^ swz(k).  Bits 0-3 of
+// swz spread a column of the core over all banks (the right-hand step stores it that way, lanes
+// along k); bit 4, used when a row spans a whole number of bank wraps, keeps the four k rows of
+// one MFMA operand off each other's banks.
+#define ENVF_SLOTS 12   // prefetch registers per lane: ceil(e / 4) + ceil(p / 4) of them are used
+template <bool LEFT, int NT>
+__global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restrict__ E, const double* __restrict__ X,
+                                                           const double* __restrict__ core, double* __restrict__ out,
+                                                           int Mi, int C, int e, int p, int n, int accumulate,
+                                                           int mode, const double* __restrict__ Rdot,
+                                                           const double* __restrict__ Hmul) {
+  extern __shared__ double smem[];
+  constexpr int npad = NT * 16;
+  constexpr int SW = (NT % 2 == 0) ? 1 : 0;
+  const int K = e * p;
+  const int Kp = (K + 15) & ~15;                       // the k loop runs in groups of 16; rows K..Kp are zero
+  double* Bs = smem;                                   // [Kp][npad]
+  int* ktab = (int*)(Bs + Kp * npad);                  // [Kp] packed offsets into the wave tiles
+  double* tiles = (double*)(ktab + Kp);                // per wave: Ew[e][17], Xw[p][17]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  double* Ew = tiles + wave * (e + p) * 17;
+  double* Xw = Ew + e * 17;
+  auto swz = [](int k) { return ((k >> 1) & 15) | (SW ? ((k & 1) << 4) : 0); };
+  if (LEFT) {   // core (e, p, n) = [K][n]: lanes along a row, eight rows in flight per thread
+    constexpr int RPP = 256 / npad;
+    const int jj = tid % npad, kk = tid / npad;
+    const bool on = kk < RPP;
+    for (int k0 = kk; k0 < Kp; k0 += RPP * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = core[min(k0 + u * RPP, K - 1) * n + min(jj, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * RPP;
+        if (on && k < Kp) Bs[k * npad + (jj ^ swz(k))] = (jj < n && k < K) ? v[u] : 0.0;
+      }
+    }
+  } else {      // core (n, p, e) = [n][K]: lanes along k, eight columns in flight per thread
+    for (int k = tid; k < Kp; k += 256) {
+      const int kc = min(k, K - 1), sz = swz(k);
+#pragma unroll
+      for (int j0 = 0; j0 < npad; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = core[min(j0 + u, n - 1) * K + kc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Bs[k * npad + ((j0 + u) ^ sz)] = (j0 + u < n && k < K) ? v[u] : 0.0;
+      }
+    }
+  }
+  for (int k = tid; k < Kp; k += 256) {
+    int ei, pi;
+    if (LEFT) {
+      ei = k / p;
+      pi = k - ei * p;
+    } else {
+      pi = k / e;
+      ei = k - pi * e;
+    }
+    ktab[k] = k < K ? (ei * 17) | ((pi * 17) << 16) : 0;   // padding: any finite operand, its core row is zero
+  }
+  // Prefetch slots.  E slots (q < QE): the 16 x e block of a tile is contiguous, lane + 64 q walks
+  // it and (row, column) of each slot follows by carrying, with no division per slot.  X slots:
+  // lane = (row in tile, feature mod 4); the sample of a row is row / C.
+  const int QE = (e + 3) >> 2, QX = (p + 3) >> 2;
+  const int ntiles = (Mi + 15) >> 4;
+  const int stride = (int)gridDim.x * 4;
+  int tile = (int)blockIdx.x * 4 + wave;
+  int e_dst[ENVF_SLOTS];
+  {
+    int r = lane / e, l = lane - r * e;
+    const int dr = 64 / e, dl = 64 - dr * e;
+#pragma unroll
+    for (int q = 0; q < ENVF_SLOTS; ++q) {
+      e_dst[q] = (lane + 64 * q < 16 * e) ? l * 17 + r : -1;
+      l += dl;
+      r += dr;
+      if (l >= e) {
+        l -= e;
+        ++r;
+      }
+    }
+  }
+  double pe[ENVF_SLOTS];
+  auto fetch = [&](int t) {
+    const int row0 = t << 4;
+    const int xr = min(row0 + i, Mi - 1);
+    const double* xsrc = X + (C == 1 ? xr : xr / C) * p;
+    const double* esrc = E + row0 * e + lane;
+    const int elim = (Mi - row0) * e - lane - 1;   // last valid offset from esrc
+#pragma unroll
+    for (int q = 0; q < ENVF_SLOTS; ++q) {
+      if (q < QE)
+        pe[q] = esrc[min(64 * q, elim)];
+      else if (q < QE + QX)
+        pe[q] = xsrc[min(kq + 4 * (q - QE), p - 1)];
+    }
+  };
+  if (tile < ntiles) fetch(tile);
+  __syncthreads();
+  const int ib = i ^ (kq >> 1);                          // low swizzle bits that depend on the lane only
+  const int par = SW ? (kq & 1) : 0;
+  for (; tile < ntiles; tile += stride) {
+    const int row0 = tile << 4;
+#pragma unroll
+    for (int q = 0; q < ENVF_SLOTS; ++q) {
+      if (q < QE) {
+        if (e_dst[q] >= 0) Ew[e_dst[q]] = pe[q];
+      } else if (q < QE + QX) {
+        const int pp = kq + 4 * (q - QE);
+        if (pp < p) Xw[pp * 17 + i] = pe[q];
+      }
+    }
+    if (tile + stride < ntiles) fetch(tile + stride);
+    // Sixteen k per group (four MFMA steps per column tile).  The loop is software pipelined by
+    // hand: the offsets of group g+2 and the operands of group g+1 are in flight while group g is
+    // multiplied.  NT is a template parameter: a run-time test around an MFMA would make the
+    // compiler wait for every product.
+    d4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+    const int ng = Kp >> 4;
+    int o0[4], o1[4];
+    double ea[4], xa[4], ba[4][NT], eb[4], xb[4], bb[4][NT];
+    auto ld_off = [&](int g, int (&o)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = ktab[min(g * 16 + u * 4 + kq, Kp - 1)];
+    };
+    // odd: parity of the group, known at compile time in the unrolled loop below; with it the
+    // swizzle of row k = 16 g + 4 u + kq is a constant XOR on top of ib
+    auto ld_dat = [&](int g, int odd, const int (&o)[4], double (&ev)[4], double (&xv)[4], double (&bv)[4][NT]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ev[u] = Ew[(o[u] & 0xffff) + i];
+        xv[u] = Xw[(o[u] >> 16) + i];
+        const double* brow = Bs + min(g * 16 + u * 4 + kq, Kp - 1) * npad + (ib ^ (2 * u + 8 * odd));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[u][j] = brow[(j ^ par) << 4];
+      }
+    };
+    auto mul = [&](const double (&ev)[4], const double (&xv)[4], const double (&bv)[4][NT]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double av = ev[u] * xv[u];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(av, bv[u][j], acc[j]);
+      }
+    };
+    ld_off(0, o0);
+    ld_off(1, o1);
+    ld_dat(0, 0, o0, ea, xa, ba);
+    for (int g = 0; g < ng; g += 2) {
+      ld_dat(g + 1, 1, o1, eb, xb, bb);
+      ld_off(g + 2, o0);
+      mul(ea, xa, ba);
+      if (g + 1 < ng) {
+        ld_dat(g + 2, 0, o0, ea, xa, ba);
+        ld_off(g + 3, o1);
+        mul(eb, xb, bb);
+      }
+    }
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = row0 + kq + 4 * t;
+          const int col = j * 16 + i;
+          if (row < Mi && col < n) {
+            double* o = out + (int64_t)row * n + col;
+            *o = accumulate ? *o + acc[j][t] : acc[j][t];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = row0 + kq + 4 * t;
+        const int rc = min(row, Mi - 1);
+        const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
+        double u = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rp[min(j * 16 + i, n - 1)] : 0.0;
+        u += __shfl_xor(u, 8, 16);
+        u += __shfl_xor(u, 4, 16);
+        u += __shfl_xor(u, 2, 16);
+        u += __shfl_xor(u, 1, 16);
+        if (Hmul) u *= Hmul[rc];   // C == 1: the Hessian is one number per row
+        if (i == 0 && row < Mi) out[row] = accumulate ? out[row] + u : u;
+      }
+    }
+  }
+}
+
+static bool env_fast_ok(int e, int p, int n, size_t* lds) {
+  const int K = e * p, npad = (n + 15) & ~15;
+  const int Kp = (K + 15) & ~15;
+  const size_t bytes = ((size_t)Kp * npad) * 8 + (size_t)Kp * 4 + (size_t)4 * (e + p) * 17 * 8;
+  *lds = bytes;
+  return npad <= 64 && (e + 3) / 4 + (p + 3) / 4 <= ENVF_SLOTS && bytes <= 80 * 1024 && e * 17 < 65536 && p * 17 < 32768;
+}
+
+// Launches the resident-core kernel when the shape allows it; returns 1 when it does not (nothing launched).
+static int env_fast_launch(bool left, const double* E, const double* X, const double* core, double* out, int64_t M,
+                           int C, int e, int p, int n, int accumulate, int mode, const double* Rdot,
+                           const double* Hmul, hipStream_t st) {
+  size_t flds;
+  if (!(env_fast_ok(e, p, n, &flds) && M * (int64_t)(e > n ? e : n) < (1ll << 31) && p <= 64)) return 1;
+  const int64_t ntiles = (M + 15) >> 4;
+  const unsigned grid = (unsigned)((ntiles + 3) / 4 < 512 ? (ntiles + 3) / 4 : 512);
+  const int nt = (n + 15) >> 4;
+  static bool big_lds_set = false;   // dynamic LDS above 64 KiB has to be allowed once per kernel
+  const void* variants[8] = {(const void*)env_fast_kernel<true, 1>,  (const void*)env_fast_kernel<true, 2>,
+                             (const void*)env_fast_kernel<true, 3>,  (const void*)env_fast_kernel<true, 4>,
+                             (const void*)env_fast_kernel<false, 1>, (const void*)env_fast_kernel<false, 2>,
+                             (const void*)env_fast_kernel<false, 3>, (const void*)env_fast_kernel<false, 4>};
+  if (!big_lds_set) {
+    for (int v = 0; v < 8; ++v)
+      if (hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        return TTK_ELAUNCH;
+    big_lds_set = true;
+  }
+  int Mi = (int)M;
+  void* args[] = {(void*)&E, (void*)&X, (void*)&core, (void*)&out, (void*)&Mi, (void*)&C, (void*)&e, (void*)&p,
+                  (void*)&n, (void*)&accumulate, (void*)&mode, (void*)&Rdot, (void*)&Hmul};
+  if (hipLaunchKernel(variants[(left ? 0 : 4) + nt - 1], dim3(grid), dim3(256), args, flds, st) != hipSuccess)
+    return TTK_ELAUNCH;
+  return ttk_launch_status();
+}
+
 static int env_step_launch(bool left, const double* E, const double* X, const double* core, double* out, int64_t M,
                            int C, int e, int p, int n, int accumulate, hipStream_t st) {
+  const int frc = env_fast_launch(left, E, X, core, out, M, C, e, p, n, accumulate, 0, nullptr, nullptr, st);
+  if (frc != 1) return frc;
   const int K = e * p;
   int KC = round_up(K, 4);
   const int kc_max = (48 * 1024) / (64 * 8);  // 96 rows of 64 doubles = 48 KiB
@@ -684,7 +923,7 @@ static RhsDims rhs_dims(int64_t S, int C, int rl, int p, int rr) {
   return d;
 }
 
-__global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ L, const double* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ L, const double* __restrict__ X,
                                                    const double* __restrict__ R, const double* __restrict__ g,
                                                    int64_t S, int C, int rl, int p, int rr, RhsDims rd,
                                                    double* __restrict__ partial) {
@@ -770,6 +1009,18 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ L, 
       }
     }
   }
+}
+
+// hu[s,d] = sum_c H[s,c,d] u[s,c]
+__global__ __launch_bounds__(256) void jvp_hess_kernel(const double* __restrict__ u, const double* __restrict__ H,
+                                                        double* __restrict__ hu, int64_t S, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * C) return;
+  const int64_t s = idx / C;
+  const int d = (int)(idx - s * C);
+  double v = 0.0;
+  for (int c = 0; c < C; ++c) v += H[(s * C + c) * C + d] * u[s * C + c];
+  hu[idx] = v;
 }
 
 // u[s,c] = sum_r tmp[s,c,r] R[s,r];  hu[s,d] = sum_c H[s,c,d] u[s,c]
@@ -903,7 +1154,7 @@ __device__ __forceinline__ double rcp_f64(double d) {
   return y;
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ aug, int ld, int j, int fuse,
+__global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__ aug, int ld, int j, int fuse,
                                                             int* __restrict__ info) {
   __shared__ double T[CHB][CHB + 1];
   __shared__ double B[CHB][CHB + 1];
@@ -1983,7 +2234,15 @@ int ttk_jvp_f64(const double* L, const double* X, const double* R, const double*
                 double* hu, int64_t S, int C, int rl, int p, int rr, void* stream) {
   if (!L || !X || !R || !H || !v || !tmp || !hu || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  int rc = env_step_launch(true, L, X, v, tmp, S * C, C, rl, p, rr, 0, st);
+  // resident-core kernel with the dot against R (and, for one output, the Hessian) in its epilogue:
+  // the (S*C, rr) intermediate never reaches memory
+  int rc = env_fast_launch(true, L, X, v, C == 1 ? hu : tmp, S * C, C, rl, p, rr, 0, 1, R, C == 1 ? H : nullptr, st);
+  if (rc == TTK_OK && C > 1) {
+    hipLaunchKernelGGL(jvp_hess_kernel, dim3((unsigned)((S * C + 255) / 256)), dim3(256), 0, st, tmp, H, hu, S, C);
+    return ttk_launch_status();
+  }
+  if (rc != 1) return rc;
+  rc = env_step_launch(true, L, X, v, tmp, S * C, C, rl, p, rr, 0, st);
   if (rc != TTK_OK) return rc;
   hipLaunchKernelGGL(jvp_finish_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, tmp, R, H, hu, S, C, rr);
   return ttk_launch_status();

@@ -22,6 +22,8 @@ def _rand(shape, seed):
 SHAPES = [  # S, C, rl, p, rr
     (96, 1, 4, 3, 4), (130, 3, 6, 4, 6), (77, 2, 1, 5, 4), (64, 1, 4, 3, 1), (513, 1, 32, 6, 32),
     (200, 2, 7, 5, 9), (1, 1, 3, 2, 3), (300, 1, 24, 50, 24), (100, 9, 9, 17, 20), (257, 1, 48, 5, 70),
+    # many ragged 16-row tiles per wave of the resident-core kernel, 1..4 column tiles
+    (5000, 3, 8, 3, 40), (40999, 1, 8, 4, 64), (2001, 2, 16, 2, 17), (70001, 1, 32, 6, 32), (9000, 1, 40, 3, 8),
 ]
 
 
@@ -38,6 +40,12 @@ def test_env_steps(S, C, rl, p, rr):
     Lk = _rand((S, C, rr), 5)
     y = ops.predict(Lk.to(dev), R.to(dev))
     assert G.rel_err(y, torch.einsum('scr,sr->sc', Lk, R)) < TOL
+    # accumulating form: out += step
+    base_l, base_r = _rand((S, C, rr), 6), _rand((S, rl), 7)
+    out = ops.env_step_left(E.to(dev), X.to(dev), core.to(dev), out=base_l.to(dev))
+    assert G.rel_err(out, base_l + O.env_left_step(E, core, X)) < TOL
+    out = ops.env_step_right(R.to(dev), X.to(dev), core.to(dev), out=base_r.to(dev))
+    assert G.rel_err(out, base_r + O.env_right_step(R, core, X)) < TOL
 
 
 @gpu
