@@ -154,6 +154,25 @@ int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream
 int ttk_dot_f64(const double* x, const double* y, double* out, int64_t n, void* stream);
 int ttk_axpy_f64(const double* a, double sign, const double* x, double* y, int64_t n, void* stream);
 
+/* The vector half of a Krylov iteration as one launch of one workgroup (the vectors have the
+ * size of one core), so that an iteration is the operator product plus one more kernel and the
+ * host never waits inside the loop.
+ *
+ * ttk_cg_update_f64: conjugate gradients with the recurrence and stopping rule of
+ * scipy.sparse.linalg.cg, which scipy_swipe hands the local system to (tensor/network.py:897-924).
+ * state (4 doubles on the device) = [rho = <r,r>, atol = rtol*||b||, stopped, updates done].  If
+ * sqrt(rho) < atol the call only sets stopped = 1 and leaves x, r, p untouched (calls queued
+ * behind it are no-ops); otherwise  alpha = rho/<p,q>, x += alpha p, r -= alpha q,
+ * rho' = <r,r>, p = r + (rho'/rho) p, state[0] = rho', state[3] += 1.   q = A p on entry.
+ *
+ * ttk_lanczos_update_f64: iteration j >= 1 of the Lanczos recurrence of lanczos_solver
+ * (tensor/network.py:796-824) with w = A v_cur on entry:  w -= betas[j-1] v_prev (skipped when
+ * v_prev is NULL: the reference's zero vector of the first iteration), alphas[j-1] = <w,v_cur>,
+ * w -= alphas[j-1] v_cur, betas[j] = ||w||, v_next = w / betas[j]. */
+int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* stream);
+int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
+                           double* betas, int j, int64_t D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1070,6 +1070,83 @@ __global__ __launch_bounds__(256) void axpy_kernel(const double* __restrict__ a,
   if (idx < n) y[idx] += sign * a[0] * x[idx];
 }
 
+// Sum over the 1024 threads of a workgroup, the same value on every thread; fixed order.
+__device__ __forceinline__ double block_sum_1024(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();   // red may still be read from the previous sum
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
+
+// The vector half of one conjugate-gradient iteration in one workgroup (the vectors have the size
+// of one core): the stopping test on the current residual, then
+//   alpha = rho / <p,q>;  x += alpha p;  r -= alpha q;  rho' = <r,r>;  p = r + (rho'/rho) p.
+// state = [rho, atol, stopped, updates done].  Once the test ||r|| < atol holds the kernel only
+// sets `stopped` and leaves x, r, p as they are, so iterations queued behind it change nothing.
+__global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x, double* __restrict__ r,
+                                                          double* __restrict__ p, const double* __restrict__ q,
+                                                          double* __restrict__ state, int64_t D) {
+  __shared__ double red[16];
+  const double rho = state[0], atol = state[1];
+  if (sqrt(rho) < atol) {
+    if (threadIdx.x == 0) state[2] = 1.0;
+    return;
+  }
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) acc += p[k] * q[k];
+  const double alpha = rho / block_sum_1024(acc, red);
+  acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    x[k] += alpha * p[k];
+    const double rn = r[k] - alpha * q[k];
+    r[k] = rn;
+    acc += rn * rn;
+  }
+  const double rho_new = block_sum_1024(acc, red);
+  const double beta = rho_new / rho;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) p[k] = r[k] + beta * p[k];
+  if (threadIdx.x == 0) {
+    state[0] = rho_new;
+    state[3] += 1.0;
+  }
+}
+
+// The vector half of one Lanczos iteration j >= 1 in one workgroup:
+//   w -= beta[j-1] v_prev;  alpha[j-1] = <w, v_cur>;  w -= alpha[j-1] v_cur;  beta[j] = ||w||;  v_next = w / beta[j].
+__global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict__ w, const double* __restrict__ v_prev,
+                                                               const double* __restrict__ v_cur,
+                                                               double* __restrict__ v_next, double* __restrict__ alphas,
+                                                               double* __restrict__ betas, int j, int64_t D) {
+  __shared__ double red[16];
+  const double bprev = betas[j - 1];
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    double wk = w[k];
+    if (v_prev) {
+      wk -= bprev * v_prev[k];
+      w[k] = wk;
+    }
+    acc += wk * v_cur[k];
+  }
+  const double a = block_sum_1024(acc, red);
+  acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    const double wk = w[k] - a * v_cur[k];
+    w[k] = wk;
+    acc += wk * wk;
+  }
+  const double bj = sqrt(block_sum_1024(acc, red));
+  for (int64_t k = threadIdx.x; k < D; k += 1024) v_next[k] = w[k] / bj;
+  if (threadIdx.x == 0) {
+    alphas[j - 1] = a;
+    betas[j] = bj;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky with the right-hand side carried as an extra block row.
 //
@@ -2287,6 +2364,20 @@ int ttk_axpy_f64(const double* a, double sign, const double* x, double* y, int64
   if (!a || !x || !y || n < 1) return TTK_EINVAL;
   hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, sign, x, y,
                      n);
+  return ttk_launch_status();
+}
+
+int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* stream) {
+  if (!x || !r || !p || !q || !state || D < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
+  return ttk_launch_status();
+}
+
+int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
+                           double* betas, int j, int64_t D, void* stream) {
+  if (!w || !v_cur || !v_next || !alphas || !betas || j < 1 || D < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next, alphas,
+                     betas, j, D);
   return ttk_launch_status();
 }
 

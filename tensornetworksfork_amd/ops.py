@@ -321,3 +321,22 @@ def gram_timing_read(max_n=512):
     if n < 0:
         _lib.check(n, "ttk_gram_timing_read")
     return [buf[i] for i in range(n)]
+
+
+def cg_update(x, r, p, q, state):
+    """One conjugate-gradient vector update in place (q = A p); see ttk_cg_update_f64.
+    state = [<r,r>, atol, stopped, updates done] on the device."""
+    rc = _lib.lib().ttk_cg_update_f64(_chk(x, "x"), _chk(r, "r"), _chk(p, "p"), _chk(q, "q"), _chk(state, "state"),
+                                      x.numel(), _stream(x))
+    _lib.check(rc, "ttk_cg_update_f64")
+
+
+def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
+    """Iteration j >= 1 of the Lanczos recurrence on w = A v_cur (in place); returns v_next.
+    alphas[j-1] and betas[j] are written on the device; v_prev may be None (first iteration)."""
+    v_next = torch.empty_like(w)
+    rc = _lib.lib().ttk_lanczos_update_f64(_chk(w, "w"), 0 if v_prev is None else _chk(v_prev, "v_prev"),
+                                           _chk(v_cur, "v_cur"), v_next.data_ptr(), _chk(alphas, "alphas"),
+                                           _chk(betas, "betas"), int(j), w.numel(), _stream(w))
+    _lib.check(rc, "ttk_lanczos_update_f64")
+    return v_next

@@ -17,36 +17,33 @@ def _cholesky_solve(A_f, rhs):
 
 def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8):
     """Lanczos-Galerkin without re-orthogonalisation (tensor/network.py:796-824).
-    alpha/beta stay on the device; the beta < tol exit is tested every
-    `check_every` iterations and the basis truncated to the first hit, which gives
-    the same result as leaving the loop at that iteration."""
+    Each iteration is the operator product plus one fused vector kernel; alpha/beta
+    stay on the device; the beta < tol exit is tested every `check_every` iterations
+    and the basis truncated to the first hit, which gives the same result as leaving
+    the loop at that iteration."""
     shape = x0.shape
     r0 = b - matvec(x0)
+    alphas = torch.zeros(max_iter, dtype=x0.dtype, device=x0.device)
+    betas = torch.zeros(max_iter + 1, dtype=x0.dtype, device=x0.device)
     beta1 = ops.dot(r0, r0).sqrt()
+    betas[0] = beta1
     V = [r0 / beta1]
-    alphas, betas = [], [beta1]
-    v_prev = torch.zeros_like(x0)
     m = 0
     for j in range(1, max_iter + 1):
         w = matvec(V[j - 1])
-        ops.axpy(betas[j - 1], v_prev, w, sign=-1.0)
-        a_j = ops.dot(w, V[j - 1])
-        ops.axpy(a_j, V[j - 1], w, sign=-1.0)
-        bj = ops.dot(w, w).sqrt()
-        alphas.append(a_j)
-        betas.append(bj)
-        v_prev = V[j - 1]
-        V.append(w / bj)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        V.append(ops.lanczos_update(w, V[j - 2] if j > 1 else None, V[j - 1], alphas, betas, j))
         m = j
         if j % check_every == 0 or j == max_iter:
-            small = (torch.stack(betas[1:]) < tol).nonzero()
+            small = (betas[1:j + 1] < tol).nonzero()
             if small.numel() > 0:
                 m = int(small[0].item()) + 1
                 break
-    a = torch.stack(alphas[:m])
+    a = alphas[:m]
     Tm = torch.diag(a)
     if m > 1:
-        off = torch.stack(betas[1:m])
+        off = betas[1:m]
         Tm = Tm + torch.diag(off, diagonal=1) + torch.diag(off, diagonal=-1)
     rhs = torch.zeros(m, dtype=x0.dtype, device=x0.device)
     rhs[0] = beta1
@@ -55,33 +52,28 @@ def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8):
     return x0 + (Vm @ yv).reshape(shape)
 
 
-def cg_solve(matvec, b, x0, maxiter, rtol):
+def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     """Conjugate gradients with scipy.sparse.linalg.cg's recurrence and stopping
     rule (||r|| < max(0, rtol*||b||) tested before each iteration; SciPy 1.15
-    _isolve/iterative.py), in float64 on the device."""
-    bnrm = ops.dot(b, b).sqrt()
-    atol = rtol * bnrm
+    _isolve/iterative.py), in float64 on the device.  The test runs inside the fused
+    vector kernel, which freezes x once it holds; the host looks at the flag every
+    `check_every` iterations only to stop queueing work."""
+    state = torch.zeros(4, dtype=b.dtype, device=b.device)
     if x0 is None:
         xk = torch.zeros_like(b)
         r = b.clone()
     else:
         xk = x0.clone()
         r = b - matvec(xk)
-    p, rho_prev = None, None
+    p = r.clone()
+    state[0] = ops.dot(r, r)
+    state[1] = rtol * ops.dot(b, b).sqrt()
     for it in range(maxiter):
-        rr = ops.dot(r, r)
-        if bool(rr.sqrt() < atol):
-            return xk, 0
-        if it > 0:
-            p = r + (rr / rho_prev) * p
-        else:
-            p = r.clone()
         q = matvec(p)
-        alpha = rr / ops.dot(p, q)
-        ops.axpy(alpha, p, xk, sign=1.0)
-        ops.axpy(alpha, q, r, sign=-1.0)
-        rho_prev = rr
-    return xk, maxiter
+        ops.cg_update(xk, r, p, q if q.is_contiguous() else q.contiguous(), state)
+        if (it + 1) % check_every == 0 and it + 1 < maxiter and state[2].item() != 0.0:
+            break
+    return xk, (0 if state[2].item() != 0.0 else maxiter)
 
 
 def minres_solve(matvec, b, x0, maxiter, rtol):

@@ -124,8 +124,33 @@ def axpy(a, x, y, sign=1.0):
     return y.add_(sign * a * x)
 
 
+def cg_update(x, r, p, q, state):
+    rho, atol = state[0].clone(), state[1]
+    if bool(rho.sqrt() < atol):
+        state[2] = 1.0
+        return
+    alpha = rho / (p * q).sum()
+    x.add_(alpha * p)
+    r.sub_(alpha * q)
+    rho_new = (r * r).sum()
+    p.copy_(r + (rho_new / rho) * p)
+    state[0] = rho_new
+    state[3] += 1.0
+
+
+def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
+    if v_prev is not None:
+        w.sub_(betas[j - 1] * v_prev)
+    a = (w * v_cur).sum()
+    w.sub_(a * v_cur)
+    bj = (w * w).sum().sqrt()
+    alphas[j - 1] = a
+    betas[j] = bj
+    return w / bj
+
+
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "matvec solve_rhs chol_solve_gram qr dot axpy").split()
+         "matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update").split()
 
 
 def install(monkeypatch):

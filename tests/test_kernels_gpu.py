@@ -228,3 +228,34 @@ def test_two_stage_products_match_kernels():
     assert ((lp.rhs(g) - b_ref).norm() / b_ref.norm()).item() < 1e-13
     mv_ref = ops.matvec(L, X, R, H, v)
     assert ((lp.matvec_fn(H)(v) - mv_ref).norm() / mv_ref.norm()).item() < 1e-13
+
+
+@gpu
+@pytest.mark.parametrize("D", [7, 6144, 100003])
+def test_krylov_vector_updates(D):
+    """Fused CG / Lanczos vector kernels against the same recurrences in torch on the CPU."""
+    from tensornetworksfork_amd import ops
+    from tests import _kernel_standins as K
+    dev = _dev()
+    x, r, p, q = (_rand((D,), k) for k in (1, 2, 3, 4))
+    q = q + 3.0 * p                       # <p,q> well away from zero
+    for atol in (1e-9, 1e9):              # running / already converged (then nothing may change)
+        st = torch.tensor([float((r * r).sum()), atol, 0.0, 0.0], dtype=torch.float64)
+        ref = [t.clone() for t in (x, r, p)]
+        st_ref = st.clone()
+        K.cg_update(ref[0], ref[1], ref[2], q, st_ref)
+        got = [t.clone().to(dev) for t in (x, r, p)]
+        st_dev = st.to(dev)
+        ops.cg_update(got[0], got[1], got[2], q.to(dev), st_dev)
+        for g_, r_ in zip(got, ref):
+            assert G.rel_err(g_, r_) < 1e-12
+        assert G.rel_err(st_dev[:1], st_ref[:1]) < 1e-12 and torch.equal(st_dev[1:].cpu(), st_ref[1:])
+    for j, vp in ((1, None), (3, _rand((D,), 6))):
+        w, vc = _rand((D,), 7), _rand((D,), 8)
+        al, be = torch.zeros(5, dtype=torch.float64), torch.rand(6, dtype=torch.float64)
+        w_ref, al_ref, be_ref = w.clone(), al.clone(), be.clone()
+        vn_ref = K.lanczos_update(w_ref, vp, vc, al_ref, be_ref, j)
+        w_dev, al_dev, be_dev = w.to(dev), al.to(dev), be.to(dev)
+        vn = ops.lanczos_update(w_dev, None if vp is None else vp.to(dev), vc.to(dev), al_dev, be_dev, j)
+        assert G.rel_err(vn, vn_ref) < 1e-12 and G.rel_err(w_dev, w_ref) < 1e-12
+        assert G.rel_err(al_dev, al_ref) < 1e-12 and G.rel_err(be_dev, be_ref) < 1e-12
