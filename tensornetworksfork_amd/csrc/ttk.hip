@@ -897,116 +897,193 @@ __global__ __launch_bounds__(256) void gram_expand_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------
 // Right-hand side / J^T u:  b[l,(p,r)] = sum_s GL[s,l] * X[s,p] R[s,r],  GL[s,l] = sum_c g[s,c] L[s,c,l].
 // GEMM view: rows l (rl), columns (p,r), contraction over the samples of one slab.
-// A workgroup owns a slab; each wave holds up to 6 output tiles at a time.
+// A workgroup owns a slab of samples and streams it through LDS in chunks (the next chunk's
+// loads are in flight while the current one is multiplied); each wave owns a block of 2 x 3
+// output tiles, so that per four samples 2 + 3*2 operand reads and 3 multiplies feed 6 MFMAs.
+// With one output (C == 1) the gradient scales the feature factor while it is staged,
+// otherwise GL is formed by a small kernel first.  Every slab writes its own partial result;
+// a second kernel adds the slabs in fixed order.
+// LDS row of a sample: [ A (rl) | X (p) | R (rr) | .. | 0 ], row stride W = 16 mod 32 doubles so that
+// the four sample rows of one MFMA operand fall on different banks.
 // ---------------------------------------------------------------------------------------
+#define RHS_QA 8   // prefetch registers per thread for the A, X and R parts of a chunk
+#define RHS_QX 2
+#define RHS_QR 8
 struct RhsDims {
-  int mt, ntl, T, nslabs, CH, passes;
+  int mt, ntl, bn, nblocks, passes, nslabs, CH, W;
   int64_t slab_len;
 };
+
+static int g_rhs_max_slabs = 512;
 
 static RhsDims rhs_dims(int64_t S, int C, int rl, int p, int rr) {
   RhsDims d;
   d.mt = (rl + 15) / 16;
   d.ntl = (p * rr + 15) / 16;
-  d.T = d.mt * d.ntl;
-  d.passes = (d.T + 23) / 24;
-  int64_t ns = (S + 127) / 128;
-  if (ns > 512) ns = 512;
+  d.bn = (d.ntl + 2) / 3;
+  d.nblocks = ((d.mt + 1) / 2) * d.bn;
+  d.passes = (d.nblocks + 3) / 4;
+  const int wd = rl + p + rr + 1;
+  d.W = wd <= 16 ? 16 : ((wd - 16 + 31) / 32) * 32 + 16;
+  int ch = (40 * 1024) / (d.W * 8);
+  if (ch > 64) ch = 64;
+  const int big = rl > rr ? rl : rr;
+  if (ch * big > 256 * RHS_QA) ch = 256 * RHS_QA / big;
+  if (ch * p > 256 * RHS_QX) ch = 256 * RHS_QX / p;
+  d.CH = ch / 4 * 4;
+  int64_t ns = (S + 63) / 64;
+  if (ns > g_rhs_max_slabs) ns = g_rhs_max_slabs;
   if (ns < 1) ns = 1;
   d.nslabs = (int)ns;
   d.slab_len = round_up64((S + d.nslabs - 1) / d.nslabs, 4);
-  const int width = rl + p + rr;
-  int ch = (48 * 1024) / (width * 8);
-  ch = ch / 4 * 4;
-  if (ch > 128) ch = 128;
-  d.CH = ch;
   return d;
 }
 
-__global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ L, const double* __restrict__ X,
-                                                   const double* __restrict__ R, const double* __restrict__ g,
-                                                   int64_t S, int C, int rl, int p, int rr, RhsDims rd,
-                                                   double* __restrict__ partial) {
+// GL[s,l] = sum_c g[s,c] L[s,c,l]
+__global__ __launch_bounds__(256) void rhs_gl_kernel(const double* __restrict__ g, const double* __restrict__ L,
+                                                      double* __restrict__ GL, int64_t S, int C, int rl) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * rl) return;
+  const int64_t s = idx / rl;
+  const int l = (int)(idx - s * rl);
+  double v = 0.0;
+  for (int c = 0; c < C; ++c) v += g[s * C + c] * L[(s * C + c) * rl + l];
+  GL[idx] = v;
+}
+
+// LDS destinations of the prefetch slots of one part of a chunk: the part is `width` columns of
+// CH consecutive samples, contiguous in memory; slot q of a lane holds element tid + 256 q.
+template <int NQ>
+__device__ __forceinline__ void rhs_slot_dst(int tid, int width, int W, int col0, int total, int (&dst)[NQ], int (&srow)[NQ]) {
+  int r = tid / width, c = tid - r * width;
+  const int dr = 256 / width, dc = 256 - dr * width;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    dst[q] = (tid + 256 * q < total) ? r * W + col0 + c : -1;
+    srow[q] = r;
+    c += dc;
+    r += dr;
+    if (c >= width) {
+      c -= width;
+      ++r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ A, const double* __restrict__ X,
+                                                      const double* __restrict__ R, const double* __restrict__ gx,
+                                                      int64_t S, int rl, int p, int rr, RhsDims rd,
+                                                      double* __restrict__ partial) {
   extern __shared__ double smem[];
-  const int CH = rd.CH;
+  const int CH = rd.CH, W = rd.W;
   const int N = p * rr;
-  double* GLs = smem;
-  double* Xs = GLs + (size_t)CH * rl;
-  double* Rs = Xs + (size_t)CH * p;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int slab = blockIdx.x;
   const int64_t s_begin = (int64_t)slab * rd.slab_len;
   int64_t s_end = s_begin + rd.slab_len;
   if (s_end > S) s_end = S;
   double* dst = partial + (int64_t)slab * rl * N;
+  for (int k = tid; k < CH; k += 256) smem[k * W + W - 1] = 0.0;   // the zero column padded lanes read
+  int dA[RHS_QA], dX[RHS_QX], dR[RHS_QR], rA[RHS_QA], rX[RHS_QX], rR[RHS_QR];
+  rhs_slot_dst<RHS_QA>(tid, rl, W, 0, CH * rl, dA, rA);
+  rhs_slot_dst<RHS_QX>(tid, p, W, rl, CH * p, dX, rX);
+  rhs_slot_dst<RHS_QR>(tid, rr, W, rl + p, CH * rr, dR, rR);
+  double pa[RHS_QA], px[RHS_QX], pg[RHS_QX], pr[RHS_QR];
+  // One batch of loads with clamped indices, every slot unconditionally (unused slots re-read the
+  // last element) and nothing that consumes them: a load inside a branch, or a use next to its
+  // load, is waited for on the spot, one load at a time.  Zeroing of samples past the slab end
+  // and the gradient factor are applied when the registers go to LDS.
+  auto fetch = [&](int64_t c0) {
+    const int nvalid = (int)min((int64_t)CH, s_end - c0);
+    const double* a0 = A + c0 * rl + tid;
+    const double* x0 = X + c0 * p + tid;
+    const double* r0 = R + c0 * rr + tid;
+    const double* gsrc = gx ? gx + c0 : X + c0 * p;   // without a gradient factor: any readable address, value unused
+    const int la = nvalid * rl - 1 - tid, lx = nvalid * p - 1 - tid, lr = nvalid * rr - 1 - tid;
+#pragma unroll
+    for (int q = 0; q < RHS_QA; ++q) pa[q] = a0[max(min(256 * q, la), -tid)];
+#pragma unroll
+    for (int q = 0; q < RHS_QX; ++q) {
+      px[q] = x0[max(min(256 * q, lx), -tid)];
+      pg[q] = gsrc[min(rX[q], nvalid - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < RHS_QR; ++q) pr[q] = r0[max(min(256 * q, lr), -tid)];
+  };
+  const int bm = (rd.mt + 1) >> 1;
   for (int pass = 0; pass < rd.passes; ++pass) {
-    int lrow[6], xo[6], ro[6];
-    double msk[6];
-    bool tv[6];
-    d4 acc[6];
+    const int blk = pass * 4 + wave;
+    const bool active = blk < rd.nblocks;
+    const int tm = active ? blk / rd.bn : 0, tn = active ? blk - tm * rd.bn : 0;
+    (void)bm;
+    int oA[2], oX[3], oR[3];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int t = pass * 24 + j * 4 + wave;
-      tv[j] = t < rd.T;
-      const int tmi = tv[j] ? t / rd.ntl : 0;
-      const int tni = tv[j] ? t - tmi * rd.ntl : 0;
-      const int l = tmi * 16 + i;
-      const int n = tni * 16 + i;
-      lrow[j] = l < rl ? l : 0;
-      const int nn = n < N ? n : 0;
-      xo[j] = nn / rr;
-      ro[j] = nn - xo[j] * rr;
-      msk[j] = (n < N ? 1.0 : 0.0);
-      if (l >= rl) lrow[j] = -1;
-      acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < 2; ++u) {
+      const int l = (tm * 2 + u) * 16 + i;
+      oA[u] = l < rl ? l : W - 1;
     }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int n = (tn * 3 + v) * 16 + i;
+      if (n < N) {
+        const int pn = n / rr;
+        oX[v] = rl + pn;
+        oR[v] = rl + p + (n - pn * rr);
+      } else {
+        oX[v] = oR[v] = W - 1;
+      }
+    }
+    d4 acc[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    if (s_begin < s_end) fetch(s_begin);
     for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
-      const int64_t nvalid = min((int64_t)CH, s_end - c0);
-      __syncthreads();
-      // clamped, unconditional loads (samples past the slab end repeat the last one and are zeroed)
-      for (int idx = threadIdx.x; idx < CH * rl; idx += 256) {
-        const int sl = idx / rl, l = idx - sl * rl;
-        const int64_t s = c0 + min((int64_t)sl, nvalid - 1);
-        double v = 0.0;
-        for (int c = 0; c < C; ++c) v += g[s * C + c] * L[(s * C + c) * rl + l];
-        GLs[idx] = sl < nvalid ? v : 0.0;
-      }
-      const double* gX = X + c0 * p;
-      for (int idx = threadIdx.x; idx < CH * p; idx += 256) {
-        const double v = gX[min((int64_t)idx, nvalid * p - 1)];
-        Xs[idx] = idx < nvalid * p ? v : 0.0;
-      }
-      const double* gR = R + c0 * rr;
-      for (int idx = threadIdx.x; idx < CH * rr; idx += 256) {
-        const double v = gR[min((int64_t)idx, nvalid * rr - 1)];
-        Rs[idx] = idx < nvalid * rr ? v : 0.0;
-      }
-      __syncthreads();
-      const int steps = (int)((nvalid + 3) >> 2);
-      for (int ks = 0; ks < steps; ++ks) {
-        const int s = ks * 4 + kq;
+      const int nvalid = (int)min((int64_t)CH, s_end - c0);
+      __syncthreads();   // every wave is done with the previous chunk
+      {
+        const int la = nvalid * rl - 1 - tid, lx = nvalid * p - 1 - tid, lr = nvalid * rr - 1 - tid;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          if (tv[j]) {
-            const double a = lrow[j] >= 0 ? GLs[s * rl + lrow[j]] : 0.0;
-            const double bb = Xs[s * p + xo[j]] * Rs[s * rr + ro[j]] * msk[j];
-            acc[j] = MFMA_F64(a, bb, acc[j]);
-          }
+        for (int q = 0; q < RHS_QA; ++q)
+          if (dA[q] >= 0) smem[dA[q]] = 256 * q <= la ? pa[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < RHS_QX; ++q)
+          if (dX[q] >= 0) smem[dX[q]] = 256 * q <= lx ? (gx ? px[q] * pg[q] : px[q]) : 0.0;
+#pragma unroll
+        for (int q = 0; q < RHS_QR; ++q)
+          if (dR[q] >= 0) smem[dR[q]] = 256 * q <= lr ? pr[q] : 0.0;
+      }
+      __syncthreads();
+      if (c0 + CH < s_end) fetch(c0 + CH);
+      if (active) {
+        const int steps = (nvalid + 3) >> 2;
+#pragma unroll 2
+        for (int ks = 0; ks < steps; ++ks) {
+          const double* row = smem + (ks * 4 + kq) * W;
+          double av[2], bv[3];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) av[u] = row[oA[u]];
+#pragma unroll
+          for (int v = 0; v < 3; ++v) bv[v] = row[oX[v]] * row[oR[v]];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) acc[u][v] = MFMA_F64(av[u], bv[v], acc[u][v]);
         }
       }
     }
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (tv[j]) {
-        const int t = pass * 24 + j * 4 + wave;
-        const int tmi = t / rd.ntl, tni = t - tmi * rd.ntl;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int l = tmi * 16 + kq + 4 * u;
-          const int n = tni * 16 + i;
-          if (l < rl && n < N) dst[(int64_t)l * N + n] = acc[j][u];
-        }
-      }
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int l = (tm * 2 + u) * 16 + kq + 4 * t;
+            const int n = (tn * 3 + v) * 16 + i;
+            if (l < rl && n < N) dst[(int64_t)l * N + n] = acc[u][v][t];
+          }
     }
   }
 }
@@ -1087,6 +1164,8 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red) {
 //   alpha = rho / <p,q>;  x += alpha p;  r -= alpha q;  rho' = <r,r>;  p = r + (rho'/rho) p.
 // state = [rho, atol, stopped, updates done].  Once the test ||r|| < atol holds the kernel only
 // sets `stopped` and leaves x, r, p as they are, so iterations queued behind it change nothing.
+// REG: the vectors fit eight elements per thread and stay in registers between the passes.
+template <bool REG>
 __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x, double* __restrict__ r,
                                                           double* __restrict__ p, const double* __restrict__ q,
                                                           double* __restrict__ state, int64_t D) {
@@ -1096,19 +1175,55 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
     if (threadIdx.x == 0) state[2] = 1.0;
     return;
   }
-  double acc = 0.0;
-  for (int64_t k = threadIdx.x; k < D; k += 1024) acc += p[k] * q[k];
-  const double alpha = rho / block_sum_1024(acc, red);
-  acc = 0.0;
-  for (int64_t k = threadIdx.x; k < D; k += 1024) {
-    x[k] += alpha * p[k];
-    const double rn = r[k] - alpha * q[k];
-    r[k] = rn;
-    acc += rn * rn;
+  double rho_new;
+  if (REG) {
+    double xv[8], rv[8], pv[8], qv[8];
+    const int n = (int)D;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = min((int)threadIdx.x + 1024 * u, n - 1);
+      xv[u] = x[k];
+      rv[u] = r[k];
+      pv[u] = p[k];
+      qv[u] = q[k];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += ((int)threadIdx.x + 1024 * u < n) ? pv[u] * qv[u] : 0.0;
+    const double alpha = rho / block_sum_1024(acc, red);
+    acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      xv[u] += alpha * pv[u];
+      rv[u] -= alpha * qv[u];
+      acc += ((int)threadIdx.x + 1024 * u < n) ? rv[u] * rv[u] : 0.0;
+    }
+    rho_new = block_sum_1024(acc, red);
+    const double beta = rho_new / rho;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (int)threadIdx.x + 1024 * u;
+      if (k < n) {
+        x[k] = xv[u];
+        r[k] = rv[u];
+        p[k] = rv[u] + beta * pv[u];
+      }
+    }
+  } else {
+    double acc = 0.0;
+    for (int64_t k = threadIdx.x; k < D; k += 1024) acc += p[k] * q[k];
+    const double alpha = rho / block_sum_1024(acc, red);
+    acc = 0.0;
+    for (int64_t k = threadIdx.x; k < D; k += 1024) {
+      x[k] += alpha * p[k];
+      const double rn = r[k] - alpha * q[k];
+      r[k] = rn;
+      acc += rn * rn;
+    }
+    rho_new = block_sum_1024(acc, red);
+    const double beta = rho_new / rho;
+    for (int64_t k = threadIdx.x; k < D; k += 1024) p[k] = r[k] + beta * p[k];
   }
-  const double rho_new = block_sum_1024(acc, red);
-  const double beta = rho_new / rho;
-  for (int64_t k = threadIdx.x; k < D; k += 1024) p[k] = r[k] + beta * p[k];
   if (threadIdx.x == 0) {
     state[0] = rho_new;
     state[3] += 1.0;
@@ -1117,30 +1232,63 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
 
 // The vector half of one Lanczos iteration j >= 1 in one workgroup:
 //   w -= beta[j-1] v_prev;  alpha[j-1] = <w, v_cur>;  w -= alpha[j-1] v_cur;  beta[j] = ||w||;  v_next = w / beta[j].
+template <bool REG>
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict__ w, const double* __restrict__ v_prev,
                                                                const double* __restrict__ v_cur,
                                                                double* __restrict__ v_next, double* __restrict__ alphas,
                                                                double* __restrict__ betas, int j, int64_t D) {
   __shared__ double red[16];
   const double bprev = betas[j - 1];
-  double acc = 0.0;
-  for (int64_t k = threadIdx.x; k < D; k += 1024) {
-    double wk = w[k];
-    if (v_prev) {
-      wk -= bprev * v_prev[k];
-      w[k] = wk;
+  double a, bj;
+  if (REG) {
+    double wv[8], cv[8];
+    const int n = (int)D;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = min((int)threadIdx.x + 1024 * u, n - 1);
+      wv[u] = w[k];
+      cv[u] = v_cur[k];
+      if (v_prev) wv[u] -= bprev * v_prev[k];
     }
-    acc += wk * v_cur[k];
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += ((int)threadIdx.x + 1024 * u < n) ? wv[u] * cv[u] : 0.0;
+    a = block_sum_1024(acc, red);
+    acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      wv[u] -= a * cv[u];
+      acc += ((int)threadIdx.x + 1024 * u < n) ? wv[u] * wv[u] : 0.0;
+    }
+    bj = sqrt(block_sum_1024(acc, red));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (int)threadIdx.x + 1024 * u;
+      if (k < n) {
+        w[k] = wv[u];
+        v_next[k] = wv[u] / bj;
+      }
+    }
+  } else {
+    double acc = 0.0;
+    for (int64_t k = threadIdx.x; k < D; k += 1024) {
+      double wk = w[k];
+      if (v_prev) {
+        wk -= bprev * v_prev[k];
+        w[k] = wk;
+      }
+      acc += wk * v_cur[k];
+    }
+    a = block_sum_1024(acc, red);
+    acc = 0.0;
+    for (int64_t k = threadIdx.x; k < D; k += 1024) {
+      const double wk = w[k] - a * v_cur[k];
+      w[k] = wk;
+      acc += wk * wk;
+    }
+    bj = sqrt(block_sum_1024(acc, red));
+    for (int64_t k = threadIdx.x; k < D; k += 1024) v_next[k] = w[k] / bj;
   }
-  const double a = block_sum_1024(acc, red);
-  acc = 0.0;
-  for (int64_t k = threadIdx.x; k < D; k += 1024) {
-    const double wk = w[k] - a * v_cur[k];
-    w[k] = wk;
-    acc += wk * wk;
-  }
-  const double bj = sqrt(block_sum_1024(acc, red));
-  for (int64_t k = threadIdx.x; k < D; k += 1024) v_next[k] = w[k] / bj;
   if (threadIdx.x == 0) {
     alphas[j - 1] = a;
     betas[j] = bj;
@@ -2228,6 +2376,7 @@ int ttk_debug_syrk(double* aug, int ld, int pc0, int K, int o0, int nrows, int n
 }
 int ttk_debug_syrk_tile(int ts) { g_syrk_tile = ts; return 0; }
 int ttk_debug_group(int g) { g_group4_min = g; return 0; }
+int ttk_debug_rhs_slabs(int n) { g_rhs_max_slabs = n; return 0; }
 int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
 #endif
 
@@ -2282,7 +2431,8 @@ int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {
   if (S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const RhsDims d = rhs_dims(S, C, rl, p, rr);
   if (d.CH < 4) return TTK_EINVAL;
-  return (int64_t)d.nslabs * rl * p * rr * (int64_t)sizeof(double);
+  // slab partials, then GL when there are several outputs
+  return ((int64_t)d.nslabs * rl * p * rr + (C > 1 ? S * rl : 0)) * (int64_t)sizeof(double);
 }
 
 int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C, int rl,
@@ -2291,11 +2441,19 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
   const RhsDims d = rhs_dims(S, C, rl, p, rr);
   if (d.CH < 4) return TTK_EINVAL;
   if (ws_bytes < ttk_rhs_ws_bytes(S, C, rl, p, rr)) return TTK_EWORKSPACE;
+  if (S * (int64_t)(rl > rr ? rl : rr) >= (1ll << 40)) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t D = (int64_t)rl * p * rr;
-  const size_t lds = (size_t)d.CH * (rl + p + rr) * sizeof(double);
-  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)d.nslabs), dim3(256), lds, st, L, X, R, g, S, C, rl, p, rr, d,
-                     (double*)ws);
+  const double* A = L;
+  const double* gx = g;
+  if (C > 1) {
+    double* GL = (double*)ws + (int64_t)d.nslabs * D;
+    hipLaunchKernelGGL(rhs_gl_kernel, dim3((unsigned)((S * rl + 255) / 256)), dim3(256), 0, st, g, L, GL, S, C, rl);
+    A = GL;
+    gx = nullptr;
+  }
+  const size_t lds = (size_t)d.CH * d.W * sizeof(double);
+  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, (double*)ws);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 32)
@@ -2369,15 +2527,22 @@ int ttk_axpy_f64(const double* a, double sign, const double* x, double* y, int64
 
 int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* stream) {
   if (!x || !r || !p || !q || !state || D < 1) return TTK_EINVAL;
-  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
+  if (D <= 8192)
+    hipLaunchKernelGGL(cg_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
+  else
+    hipLaunchKernelGGL(cg_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
   return ttk_launch_status();
 }
 
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, void* stream) {
   if (!w || !v_cur || !v_next || !alphas || !betas || j < 1 || D < 1) return TTK_EINVAL;
-  hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next, alphas,
-                     betas, j, D);
+  if (D <= 8192)
+    hipLaunchKernelGGL(lanczos_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
+                       alphas, betas, j, D);
+  else
+    hipLaunchKernelGGL(lanczos_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
+                       alphas, betas, j, D);
   return ttk_launch_status();
 }
 
