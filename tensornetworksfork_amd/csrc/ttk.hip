@@ -246,6 +246,34 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
   __syncthreads();
   const int ib = i ^ (kq >> 1);                          // low swizzle bits that depend on the lane only
   const int par = SW ? (kq & 1) : 0;
+  // Results leave one tile late (DEFER): a wave's stores and its prefetch loads retire in issue order,
+  // so stores issued right before the next tile's loads would be waited for together with them;
+  // issued a whole tile earlier they have long completed.  Costs NT*8 registers, so only for NT <= 2.
+  constexpr bool DEFER = NT <= 2;
+  d4 hold[NT];
+  int hold_row0 = -1;
+  auto flush = [&](const d4 (&v)[NT], int row0) {
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = row0 + kq + 4 * t;
+          const int col = j * 16 + i;
+          if (row < Mi && col < n) {
+            double* o = out + (int64_t)row * n + col;
+            *o = accumulate ? *o + v[j][t] : v[j][t];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = row0 + kq + 4 * t;
+        if (i == 0 && row < Mi) out[row] = accumulate ? out[row] + v[0][t] : v[0][t];
+      }
+    }
+  };
   for (; tile < ntiles; tile += stride) {
     const int row0 = tile << 4;
 #pragma unroll
@@ -257,7 +285,20 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
         if (pp < p) Xw[pp * 17 + i] = pe[q];
       }
     }
+    if (DEFER && hold_row0 >= 0) flush(hold, hold_row0);
     if (tile + stride < ntiles) fetch(tile + stride);
+    // mode 1: the factors of the row dot products, fetched now and used after the k loop
+    double rv[DEFER ? 4 : 1][NT], hv[DEFER ? 4 : 1];
+    if (DEFER && mode != 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rc = min(row0 + kq + 4 * t, Mi - 1);
+        const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[t][j] = rp[min(j * 16 + i, n - 1)];
+        hv[t] = Hmul ? Hmul[rc] : 1.0;
+      }
+    }
     // Sixteen k per group (four MFMA steps per column tile).  The loop is software pipelined by
     // hand: the offsets of group g+2 and the operands of group g+1 are in flight while group g is
     // multiplied.  NT is a template parameter: a run-time test around an MFMA would make the
@@ -305,37 +346,37 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
         mul(eb, xb, bb);
       }
     }
-    if (mode == 0) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = row0 + kq + 4 * t;
-          const int col = j * 16 + i;
-          if (row < Mi && col < n) {
-            double* o = out + (int64_t)row * n + col;
-            *o = accumulate ? *o + acc[j][t] : acc[j][t];
-          }
-        }
-      }
-    } else {
+    if (mode != 0) {   // row dot products; the result of row kq + 4 t lands in acc[0][t] of the lanes i == 0
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int row = row0 + kq + 4 * t;
-        const int rc = min(row, Mi - 1);
-        const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
-        double u = 0.0;
+        double u = 0.0, h;
+        if (DEFER) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rp[min(j * 16 + i, n - 1)] : 0.0;
+          for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rv[t][j] : 0.0;
+          h = hv[t];
+        } else {   // wide tiles have no registers to spare for the prefetch
+          const int rc = min(row0 + kq + 4 * t, Mi - 1);
+          const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rp[min(j * 16 + i, n - 1)] : 0.0;
+          h = Hmul ? Hmul[rc] : 1.0;
+        }
         u += __shfl_xor(u, 8, 16);
         u += __shfl_xor(u, 4, 16);
         u += __shfl_xor(u, 2, 16);
         u += __shfl_xor(u, 1, 16);
-        if (Hmul) u *= Hmul[rc];   // C == 1: the Hessian is one number per row
-        if (i == 0 && row < Mi) out[row] = accumulate ? out[row] + u : u;
+        acc[0][t] = u * h;   // h: C == 1, the Hessian is one number per row (else 1)
       }
     }
+    if (DEFER) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) hold[j] = acc[j];
+      hold_row0 = row0;
+    } else {
+      flush(acc, row0);
+    }
   }
+  if (DEFER && hold_row0 >= 0) flush(hold, hold_row0);
 }
 
 static bool env_fast_ok(int e, int p, int n, size_t* lds) {
