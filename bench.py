@@ -153,12 +153,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.set_default_dtype(torch.float64)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: TTK_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges through gloo
+    rehearse = os.environ.get("TTK_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from tensornetworksfork_amd import ops

@@ -1345,7 +1345,8 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict
 // [A b; b^T .] = [L 0; y^T .][L^T y; 0 .] the forward substitution y = L^-1 b falls out of
 // the panel solves of that extra row.  Per 64-column panel j:
 //   chol_panel_kernel : L_jj = chol(A_jj) and L_ij = A_ij L_jj^-T for every block row i > j, in
-//                       one launch (the diagonal block is factorised by every workgroup);
+//                       one launch (the diagonal block is factorised by every workgroup; L_jj is
+//                       stored beside the matrix, A_jj itself stays as it was);
 //   chol_syrk_kernel  : A_ik -= L_i,panel * L_k,panel^T on the lower trailing blocks (MFMA).
 // Panels are applied to the trailing matrix two at a time (K = 128) so that the trailing
 // matrix is swept half as often; the block column in between gets a narrow K = 64 update
@@ -1421,7 +1422,7 @@ __device__ __forceinline__ double rcp_f64(double d) {
 }
 
 __global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__ aug, int ld, int j, int fuse,
-                                                            int* __restrict__ info) {
+                                                            int* __restrict__ info, double* __restrict__ Lfac) {
   __shared__ double T[CHB][CHB + 1];
   __shared__ double B[CHB][CHB + 1];
   __shared__ double S0[CHB][CHB + 1];
@@ -1599,9 +1600,12 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__
   }
   if (!own) {
     if (wave == 0 && bad && lane == 0 && *info == 0) *info = j * CHB + badcol + 1;
+    // The factor of the diagonal block goes to its own buffer, never over A_jj: the other workgroups
+    // of this launch read A_jj whenever they happen to start.
+    double* Ld = Lfac + (int64_t)j * CHB * CHB;
     for (int idx = tid; idx < CHB * CHB; idx += 256) {
       const int rr_ = idx >> 6, cc = idx & 63;
-      if (cc <= rr_) diag[(int64_t)rr_ * ld + cc] = T[rr_][cc];
+      Ld[idx] = (cc <= rr_) ? T[rr_][cc] : 0.0;
     }
   } else {
     for (int idx = tid; idx < CHB * CHB; idx += 256) {
@@ -1613,18 +1617,18 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__
 }
 
 // invL[j] = inverse of the lower-triangular diagonal block L_jj, all blocks in one launch
-// (needed only by the backward substitution).  One column per 4 lanes, no barrier in the
+// (needed only by the backward substitution).  L_jj is where the panel kernel left it: in
+// invL[j] itself, which this kernel overwrites after it has the block in LDS.  One column per 4 lanes, no barrier in the
 // column loop: lane q writes and re-reads exactly the entries Z[i][col] with i % 4 == q.
-__global__ __launch_bounds__(256) void chol_inv_kernel(const double* __restrict__ aug, int ld,
-                                                        double* __restrict__ invL_all) {
+__global__ __launch_bounds__(256) void chol_inv_kernel(double* __restrict__ invL_all) {
   __shared__ double T[CHB][CHB + 1];
   __shared__ double Z[CHB][CHB + 1];
   const int tid = threadIdx.x;
   const int j = blockIdx.x;
-  const double* blk = aug + ((int64_t)j * CHB) * ld + (int64_t)j * CHB;
+  const double* blk = invL_all + (int64_t)j * CHB * CHB;
   for (int idx = tid; idx < CHB * CHB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
-    T[r][c] = (c <= r) ? blk[(int64_t)r * ld + c] : 0.0;
+    T[r][c] = (c <= r) ? blk[idx] : 0.0;
     Z[r][c] = 0.0;
   }
   __syncthreads();
@@ -2441,7 +2445,7 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   int base = -1;   // first panel of an open group of four
   for (int j = 0; j < nb; ++j) {
     // odd panels first absorb the previous panel's update of their own block column
-    hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nbr - j)), dim3(256), 0, st, aug, ld, j, j & 1, info, invL);
     if (j + 1 >= nb) break;
     if (base < 0) {
       if (j & 1) {
@@ -2457,7 +2461,7 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
       base = -1;
     }
   }
-  hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, invL);
+  hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, invL);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   for (int jhi = nb - 1; jhi >= 0; jhi -= BKG) {
