@@ -602,6 +602,7 @@ struct GramDims {
   int reps[GRAM_MAX_CLASSED], repof[GRAM_MAX_CLASSED];
 };
 
+static int g_gram_slabs = 0;   // > 0: slab count forced (experiments)
 static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym, int nrep = 0) {
   GramDims d;
   d.classed = 0;
@@ -641,7 +642,7 @@ static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym, int 
     if (want > 64) want = 64;
     best = want < 1 ? 1 : want;
   }
-  d.nslabs = best;
+  d.nslabs = g_gram_slabs > 0 ? g_gram_slabs : best;
   d.slab_len = round_up64((S + d.nslabs - 1) / d.nslabs, 4);
   // chunk of samples staged in LDS: (2*C*rl + p + rr) doubles per sample, <= 56 KiB
   const int width = 2 * C * rl + d.NX + rr + 1;
@@ -2422,6 +2423,7 @@ int ttk_debug_syrk(double* aug, int ld, int pc0, int K, int o0, int nrows, int n
 int ttk_debug_syrk_tile(int ts) { g_syrk_tile = ts; return 0; }
 int ttk_debug_group(int g) { g_group4_min = g; return 0; }
 int ttk_debug_rhs_slabs(int n) { g_rhs_max_slabs = n; return 0; }
+int ttk_debug_gram_slabs(int n) { g_gram_slabs = n; return 0; }
 int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
 #endif
 
