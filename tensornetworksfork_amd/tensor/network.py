@@ -36,6 +36,7 @@ class TensorNetwork:
         self._current = None
         self._shard = None
         self._pending = None
+        self._spec = None
         self._engine = self._make_engine()
 
     def _make_engine(self):
@@ -282,30 +283,67 @@ class TensorNetwork:
         return x.reshape(b.shape)
 
     # ------------------------------------------------------------------ one node update on the full data
-    def _site_update(self, d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step, min_norm, max_norm,
-                     want_loss):
-        """Gram + RHS over all samples, solve, update the node.  Returns the
-        mean-of-batch-means loss (float, or None if not requested)."""
+    def _state_sig(self):
+        """Identity + version of every parameter tensor: what a local problem depends on."""
+        inputs = set(self.input_nodes)
+        return tuple((id(n.tensor), n.tensor._version) for n in self.nodes if n not in inputs)
+
+    def _site_front(self, d, node, y, loss_fn, batch_size, want_loss):
+        """Everything of a node update that does not move a node: local problem, loss, gradient,
+        right-hand side and Gram matrix (into the workspace), all queued on the stream."""
         lp = self._engine.local(d, node)
-        core = lp.core
         y_pred = self._engine.output_at(d, node, lp)  # the output is linear in every single node
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
         total = self._batch_mean_loss(d, loss, batch_size) if want_loss else None
-        m = method.lower()
-        if m not in ('exact', 'ridge_exact', 'cholesky') and not m.startswith('ridge_cholesky'):
-            raise ValueError(f"Unknown method: {method}")
-        if eps_ == 0 and m == 'ridge_exact':
-            m = 'exact'
-        ridged = m == 'ridge_exact' or m.startswith('ridge_cholesky')
-        ridge = 2 * eps_ if ridged else 0.0
         b = lp.rhs(g)
+        front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None}
         if lp.compressed_gram(self._hessian_symmetric(H)):
             # compressed symmetric Gram in the workspace, own Cholesky on it
             ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
                 self._shard.allreduce_sum_(ws.compressed)
                 self._shard.allreduce_sum_(b)
+            front["ws"] = ws
+        else:
+            # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
+            A_f = lp.dense_gram(H)
+            if d.sharded:
+                self._shard.allreduce_sum_(A_f)
+                self._shard.allreduce_sum_(b)
+            front["A_f"] = A_f
+        return front
+
+    def _speculate(self, d, node, y, loss_fn, batch_size, want_loss):
+        """Queue the front half of the NEXT node's update before the host waits for anything of the
+        current one (pivot flag, callbacks with their own host reads): the GPU then always has the
+        next Gram matrix to work on.  Nothing here moves a node; the result is used only if no
+        parameter tensor has changed by the time the node is visited, else it is dropped."""
+        key = (id(d), id(node), id(y), id(loss_fn), batch_size, want_loss, self._state_sig())
+        alive = [n.tensor for n in self.nodes]   # held so that no id in the key can be reused meanwhile
+        self._spec = (key, self._site_front(d, node, y, loss_fn, batch_size, want_loss), alive)
+
+    def _site_update(self, d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step, min_norm, max_norm,
+                     want_loss):
+        """Gram + RHS over all samples, solve, update the node.  Returns the
+        mean-of-batch-means loss (float, or None if not requested)."""
+        m = method.lower()
+        if m not in ('exact', 'ridge_exact', 'cholesky') and not m.startswith('ridge_cholesky'):
+            raise ValueError(f"Unknown method: {method}")
+        spec, self._spec = self._spec, None
+        front = None
+        if spec is not None and spec[0] == (id(d), id(node), id(y), id(loss_fn), batch_size, want_loss, self._state_sig()):
+            front = spec[1]
+        if front is None:
+            front = self._site_front(d, node, y, loss_fn, batch_size, want_loss)
+        lp, total, b = front["lp"], front["total"], front["b"]
+        core = lp.core
+        if eps_ == 0 and m == 'ridge_exact':
+            m = 'exact'
+        ridged = m == 'ridge_exact' or m.startswith('ridge_cholesky')
+        ridge = 2 * eps_ if ridged else 0.0
+        if front["ws"] is not None:
+            ws = front["ws"]
             scale = ops.gram_scale(ws)
             if m in ('exact', 'ridge_exact'):
                 A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=self._engine.dense_buffer(lp.D, b.device))
@@ -323,11 +361,7 @@ class TensorNetwork:
                 self._pending = (info, [(n, n.tensor, list(n.dim_labels), list(n.left_labels), list(n.right_labels))
                                         for n in dict.fromkeys(list(self.main_nodes) + [node])])
         else:
-            # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
-            A_f = lp.dense_gram(H)
-            if d.sharded:
-                self._shard.allreduce_sum_(A_f)
-                self._shard.allreduce_sum_(b)
+            A_f = front["A_f"]
             scale = A_f.diagonal().abs().mean()
             scale = torch.where(scale == 0, torch.ones_like(scale), scale)
             A_f.div_(scale)
@@ -400,6 +434,7 @@ class TensorNetwork:
                 raise TypeError(f"accumulating_swipe() got an unexpected keyword argument '{k_}'")
         self._require_chain()
         self._pending = None
+        self._spec = None
         d = self._data_for(x, shard=self._shard)
         self._current = d
         device = d.xs[0].device
@@ -439,17 +474,18 @@ class TensorNetwork:
                                                  min_norm, max_norm, want_loss)
                     if orthonormalize:
                         (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
+                    if i + 1 < len(order) and method != 'gradient':
+                        # the next node's Gram matrix is queued before the host waits for the pivot flag
+                        # and before the callbacks take the host (see _speculate)
+                        nxt = order[i + 1]
+                        if not (nxt in self.node_indices and self.node_indices[nxt] == self.node_indices.get(last[other])):
+                            self._speculate(d, nxt, y, loss_fn, batch_size, want_loss)
                     self._settle()
                 except torch.linalg.LinAlgError:
+                    self._spec = None
                     if verbose and verbose > 0:
                         print(f"Singular system for node {node.name}")
                     return False
-                if i + 1 < len(order) and method != 'gradient':
-                    # queue the next node's environments before the callbacks take the host (their
-                    # results are cached by node identity, so a callback that changes nodes is safe)
-                    nxt = order[i + 1]
-                    if not (nxt in self.node_indices and self.node_indices[nxt] == self.node_indices.get(last[other])):
-                        self._engine.prefetch(d, nxt)
                 if isinstance(loss, torch.Tensor):
                     loss = loss.item()
                 if verbose and verbose > 1:
