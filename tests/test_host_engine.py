@@ -57,3 +57,49 @@ def test_other_topologies_host_logic(name, cpu_kernels):
 
 def test_conv_many_patches_host_logic(cpu_kernels, monkeypatch):
     conv.check_many_patches("cpu", monkeypatch)
+
+
+def _meddling_sweep(device, speculate):
+    """Two sweeps during which a callback changes nodes behind the engine's back: the node visited
+    next is scaled in place after every update, and one node is replaced by a new tensor."""
+    import torch
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    from tensornetworksfork_amd.tensor.network import TensorNetwork
+    torch.set_default_dtype(torch.float64)
+    layer = TensorTrainLayer(5, 3, 3, output_shape=1, seed=3).to(device)
+    tn = layer.tensor_network
+    used = []
+    if not speculate:
+        tn._speculate = lambda *a, **k: None
+    else:
+        orig = TensorNetwork._site_front
+
+        def counting_front(self, *a, **k):
+            used.append(1)
+            return orig(self, *a, **k)
+        tn._site_front = counting_front.__get__(tn)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(60, 3, generator=g).to(device)
+    y = torch.rand(60, 1, generator=g).to(device)
+    visits = []
+
+    def meddle(NS, node):
+        visits.append(node)
+        i = tn.main_nodes.index(node)
+        nxt = tn.main_nodes[(i + 1) % len(tn.main_nodes)]
+        nxt.tensor.mul_(1.01)                                   # in place: same tensor object, new version
+        if len(visits) == 3:
+            tn.main_nodes[0].tensor = tn.main_nodes[0].tensor * 0.99   # a new tensor object
+    assert tn.accumulating_swipe(x, y, SquareBregFunction(), method="ridge_cholesky", eps=1.0, num_swipes=2,
+                                 batch_size=16, block_callback=meddle)
+    return [n.tensor.detach().cpu().clone() for n in tn.main_nodes], len(used)
+
+
+def test_speculative_front_is_dropped_when_nodes_change(cpu_kernels):
+    import torch
+    ref, _ = _meddling_sweep("cpu", speculate=False)
+    got, fronts = _meddling_sweep("cpu", speculate=True)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert fronts > len(ref)      # every queued front was dropped and recomputed
