@@ -593,7 +593,7 @@ __host__ __device__ __forceinline__ int tri_index(int i, int j, int n) {  // req
 
 #define GRAM_MAX_CLASSED 64   // pair classes are honoured up to this many (p,q) pairs (p <= 10)
 struct GramDims {
-  int MP, MPpad, NX, NR, NRpad, ntm, ntn, nbp, ntiles, ngroups, nslabs, CH;
+  int MP, MPpad, NX, NR, NRpad, ntm, ntn, nbp, ntiles, ngroups, nslabs, CH, bufd;
   int64_t slab_len, gsize;
   // Feature-pair classes: pairs (p,q) whose products X_p X_q coincide for every sample (e.g.
   // powers of one variable: X_p X_q = x^(p+q)) share one slice of the Gram.  Only the nrep
@@ -644,11 +644,12 @@ static GramDims gram_dims(int64_t S, int C, int rl, int p, int rr, int sym, int 
   }
   d.nslabs = g_gram_slabs > 0 ? g_gram_slabs : best;
   d.slab_len = round_up64((S + d.nslabs - 1) / d.nslabs, 4);
-  // chunk of samples staged in LDS: (2*C*rl + p + rr) doubles per sample, <= 56 KiB
+  // chunk of samples in LDS: W doubles per sample, two buffers of at most 32 KiB each
   const int width = 2 * C * rl + d.NX + rr + 1;
-  int ch = (16 * 256) / width;   // GRAM_NLD (16) loads per thread cover one chunk (32 KiB of LDS at most)
+  int ch = (32 * 1024) / (width * 8);
   ch = ch / 4 * 4;
   if (ch > 64) ch = 64;
+  d.bufd = ((ch * width * 8 + 1023) / 1024) * 128;
   d.CH = ch;
   return d;
 }
@@ -666,11 +667,13 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
                                                          double* __restrict__ F) {
   const int CW = C * rl, NX = p * (p + 1) / 2, W = 2 * CW + NX + rr + 1;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= S * W) return;
+  if (idx >= ((S + 3) & ~(int64_t)3) * W) return;
   const int64_t s_ = idx / W;
   const int j = (int)(idx - s_ * W);
   double v = 0.0;
-  if (j < CW) {
+  if (s_ >= S) {
+    // rows up to the next multiple of four exist and are zero: the Gram kernel multiplies samples four at a time
+  } else if (j < CW) {
     v = L[s_ * CW + j];
   } else if (j < 2 * CW) {
     const int d = (j - CW) / rl, l = (j - CW) - d * rl;
@@ -685,53 +688,71 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
   F[idx] = v;
 }
 
-#define GRAM_NLD 16
-// One chunk = `total` consecutive doubles of F starting at `g`; elements past `valid` (end of
-// the slab) read as zero.  The loads are unconditional (clamped index) so that they leave as
-// one batch; a load under a per-element branch would be waited for one by one.
-__device__ __forceinline__ void gram_chunk_load(const double* __restrict__ g, int valid, int tid,
-                                                double (&v)[GRAM_NLD]) {
-#pragma unroll
-  for (int e = 0; e < GRAM_NLD; ++e) {
-    const int idx = e * 256 + tid;
-    const double x = g[min(idx, valid - 1)];
-    v[e] = idx < valid ? x : 0.0;
+// One chunk = consecutive rows of F, copied as they are into one of two LDS buffers by
+// global_load_lds (each lane moves 16 bytes, a wave instruction 1 KiB to a wave-uniform LDS base):
+// no staging registers, no LDS store phase, and the copy of the next chunk runs under the
+// products of the current one.  Lanes past the end of the chunk re-read its last 16 bytes into
+// the slack behind the image (buffers are whole KiB).
+__device__ __forceinline__ void gram_chunk_copy(const double* __restrict__ g, int doubles, double* lds, int wave,
+                                                int lane) {
+  const int units = doubles >> 1;   // 16-byte units; doubles is even (rows are copied four at a time)
+  const char* src = (const char*)g;
+  for (int it = wave; it * 64 < units; it += 4) {
+    const int u = min(it * 64 + lane, units - 1);
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)u * 16),
+                                     (void __attribute__((address_space(3)))*)((char*)lds + it * 1024), 16, 0, 0);
   }
 }
 
 // The products of one staged chunk for one wave tile: per group of 4 samples the operands
 // P[a] = H_l L_m (x XX_b) and Q[c] = R_r R_t are formed from the chunk image and multiplied
 // on the matrix cores.  TWO = the tile carries two (p,q) pairs that share P and Q.
-template <bool C1, bool TWO>
-__device__ __forceinline__ void gram_steps(const double* __restrict__ smem, int steps, int kq, int W, int C, int rl,
-                                           int oX0, int oX1, const int (&oH)[3], const int (&oL)[3],
-                                           const int (&oR1)[3], const int (&oR2)[3], d4 (&acc)[2][3][3]) {
-  for (int ks = 0; ks < steps; ++ks) {
-    const double* row = smem + (ks * 4 + kq) * W;
-    const double xx0 = row[oX0], xx1 = TWO ? row[oX1] : 0.0;
-    double aop0[3], aop1[3], bop[3];
+// fp64 multiplies and fp64 MFMA share one datapath; the arrangement below - the operands of one
+// group of 4 samples formed in one block, then its 18 MFMAs - measured fastest: multiplies of the
+// next group placed between the MFMAs (one at a time, or as one block after the first six) cost
+// 3-5 %, two groups per block (NS = 2) 7 %.
+template <bool C1, bool TWO, int NS>
+__device__ __forceinline__ void gram_step_block(const double* __restrict__ row, int W, int C, int rl, int oX0, int oX1,
+                                                const int (&oH)[3], const int (&oL)[3], const int (&oR1)[3],
+                                                const int (&oR2)[3], d4 (&acc)[2][3][3]) {
+  double aop0[NS][3], aop1[NS][3], bop[NS][3];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    const double* r = row + n * 4 * W;
+    const double xx0 = r[oX0], xx1 = TWO ? r[oX1] : 0.0;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       double pa;
       if (C1) {
-        pa = row[oH[u]] * row[oL[u]];
+        pa = r[oH[u]] * r[oL[u]];
       } else {
         pa = 0.0;
         if (oL[u] != W - 1)
-          for (int d = 0; d < C; ++d) pa += row[oH[u] + d * rl] * row[oL[u] + d * rl];
+          for (int d = 0; d < C; ++d) pa += r[oH[u] + d * rl] * r[oL[u] + d * rl];
       }
-      aop0[u] = pa * xx0;
-      if (TWO) aop1[u] = pa * xx1;
-      bop[u] = row[oR1[u]] * row[oR2[u]];
+      aop0[n][u] = pa * xx0;
+      if (TWO) aop1[n][u] = pa * xx1;
+      bop[n][u] = r[oR1[u]] * r[oR2[u]];
     }
+  }
+#pragma unroll
+  for (int n = 0; n < NS; ++n)
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int v = 0; v < 3; ++v) {
-        acc[0][u][v] = MFMA_F64(aop0[u], bop[v], acc[0][u][v]);
-        if (TWO) acc[1][u][v] = MFMA_F64(aop1[u], bop[v], acc[1][u][v]);
+        acc[0][u][v] = MFMA_F64(aop0[n][u], bop[n][v], acc[0][u][v]);
+        if (TWO) acc[1][u][v] = MFMA_F64(aop1[n][u], bop[n][v], acc[1][u][v]);
       }
-  }
+}
+
+template <bool C1, bool TWO>
+__device__ __forceinline__ void gram_steps(const double* __restrict__ smem, int steps, int kq, int W, int C, int rl,
+                                           int oX0, int oX1, const int (&oH)[3], const int (&oL)[3],
+                                           const int (&oR1)[3], const int (&oR2)[3], d4 (&acc)[2][3][3]) {
+  const double* row = smem + kq * W;
+  for (int ks = 0; ks < steps; ++ks, row += 4 * W)
+    gram_step_block<C1, TWO, 1>(row, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
 }
 
 template <bool C1>
@@ -741,7 +762,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   const int CW = C * rl;
   const int CH = gd.CH;
   const int W = 2 * CW + gd.NX + rr + 1;
-  const int total = CH * W;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int slab = blockIdx.x % gd.nslabs;
@@ -799,27 +819,28 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   const int64_t s_begin = (int64_t)slab * gd.slab_len;
   int64_t s_end = s_begin + gd.slab_len;
   if (s_end > S) s_end = S;
-  double pre[GRAM_NLD];
+  const int bufd = gd.bufd;   // doubles per LDS buffer
+  int cur = 0;
   if (s_begin < s_end)
-    gram_chunk_load(F + s_begin * W, (int)min((int64_t)CH, s_end - s_begin) * W, tid, pre);
+    gram_chunk_copy(F + s_begin * W, (((int)min((int64_t)CH, s_end - s_begin) + 3) & ~3) * W, smem, wave, lane);
   for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
     const int64_t nvalid = min((int64_t)CH, s_end - c0);
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < GRAM_NLD; ++e) {
-      const int idx = e * 256 + tid;
-      if (idx < total) smem[idx] = pre[e];
-    }
+    // this wave's part of the chunk has landed; after the barrier everybody's has, and every
+    // wave is done with the other buffer
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
     if (c0 + CH < s_end)
-      gram_chunk_load(F + (c0 + CH) * W, (int)min((int64_t)CH, s_end - c0 - CH) * W, tid, pre);
+      gram_chunk_copy(F + (c0 + CH) * W, (((int)min((int64_t)CH, s_end - c0 - CH) + 3) & ~3) * W,
+                      smem + (cur ^ 1) * bufd, wave, lane);
     if (active) {
+      const double* img = smem + cur * bufd;
       const int steps = (int)((nvalid + 3) >> 2);
       if (has1)
-        gram_steps<C1, true>(smem, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
+        gram_steps<C1, true>(img, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
       else   // the last, unpaired (p,q) of an odd count: half the products
-        gram_steps<C1, false>(smem, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
+        gram_steps<C1, false>(img, steps, kq, W, C, rl, oX0, oX1, oH, oL, oR1, oR2, acc);
     }
+    cur ^= 1;
   }
   if (active) {
     double* dst = partial + (int64_t)slab * gd.gsize;
@@ -2290,7 +2311,7 @@ int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left)
       if (ns > nslabs) nslabs = ns;
     }
   const int64_t W = 2 * (int64_t)C * rl + d.NX + rr + 1;
-  return ((int64_t)(1 + (nslabs > 1 ? nslabs : 0)) * d.gsize + S * W) * (int64_t)sizeof(double);
+  return ((int64_t)(1 + (nslabs > 1 ? nslabs : 0)) * d.gsize + (S + 3) * W) * (int64_t)sizeof(double);
 }
 
 int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R, int64_t S, int C, int rl, int p,
@@ -2322,9 +2343,9 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   double* partial = d.nslabs > 1 ? G + d.gsize : G;
   double* F = G + (int64_t)(1 + (d.nslabs > 1 ? d.nslabs : 0)) * d.gsize;
   const int64_t W = 2 * (int64_t)C * rl + d.NX + rr + 1;
-  hipLaunchKernelGGL(gram_pack_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, st, L, H, X, R, S, C, rl, p,
+  hipLaunchKernelGGL(gram_pack_kernel, dim3((unsigned)((((S + 3) & ~(int64_t)3) * W + 255) / 256)), dim3(256), 0, st, L, H, X, R, S, C, rl, p,
                      rr, F);
-  const size_t lds = (size_t)d.CH * W * sizeof(double);
+  const size_t lds = (size_t)2 * d.bufd * sizeof(double);
   const unsigned grid = (unsigned)d.ngroups * (unsigned)d.nslabs;
   const bool timed = g_ev_armed && g_ev_count < kTimingPool;
   if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
