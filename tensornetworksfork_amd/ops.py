@@ -148,6 +148,9 @@ class GramWorkspace:
         self.nbytes = int(nbytes)
         self.buf = torch.empty((self.nbytes + 7) // 8, dtype=F64, device=device)
         self.gsize = gram_gsize(int(rl), int(p), int(rr), bool(sym))
+        mp = int(rl) * (int(rl) + 1) // 2 if sym else int(rl) * int(rl)
+        self.mppad = (mp + 47) // 48 * 48    # leading extent of the compressed Gram [mppad][pairs(p,q)][nrpad]
+        self.pair_rep = None                 # feature-pair classes of the last Gram computed into it
 
     @property
     def compressed(self):
@@ -171,6 +174,7 @@ def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
                                  S, C, rl, p, rr, int(bool(sym)), None if rep is None else ctypes.cast(rep, ctypes.c_void_p),
                                  ws.buf.data_ptr(), ws.nbytes, _stream(L))
     _lib.check(rc, "ttk_gram_f64")
+    ws.pair_rep = None if pair_rep is None else [int(v) for v in pair_rep]
     return ws
 
 

@@ -43,6 +43,41 @@ class Shard:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def common_pair_classes(self, rep, n, device):
+        """Feature-pair classes that hold on EVERY rank: two pairs stay in one class only if every
+        rank's own samples put them in one (each rank detects classes on its shard).  rep: this
+        rank's class representatives (None = no classes); returns the common ones in the same form."""
+        local = torch.tensor(list(range(n)) if rep is None else [int(v) for v in rep], dtype=torch.int64)
+        if self.world > 1:
+            t = local if self.backend == "gloo" else local.to(device)
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t, group=self.group)
+            keys = list(zip(*[q.tolist() for q in parts]))
+        else:
+            keys = [(v,) for v in local.tolist()]
+        first, out = {}, []
+        for b, k in enumerate(keys):
+            out.append(first.setdefault(k, b))
+        return None if out == list(range(n)) else out
+
+    def allreduce_gram_(self, ws):
+        """Sum of the compressed Gram over ranks.  With feature-pair classes only the representative
+        slices G[:, rep, :] travel (packed, summed, copied back to every member of their class): at
+        the headline shape 24.5 MB instead of 46.8 MB.  The classes must be the common ones
+        (common_pair_classes), or ranks would disagree about the message size."""
+        G = ws.compressed
+        rep = getattr(ws, "pair_rep", None)
+        if self.world == 1 or rep is None:
+            return self.allreduce_sum_(G)
+        nx = len(rep)
+        reps = sorted(set(int(v) for v in rep))
+        pos = {r: i for i, r in enumerate(reps)}
+        G3 = G.view(-1, nx, G.numel() // (ws.mppad * nx))
+        packed = G3.index_select(1, torch.tensor(reps, device=G.device))
+        self.allreduce_sum_(packed)
+        torch.index_select(packed, 1, torch.tensor([pos[int(v)] for v in rep], device=G.device), out=G3)
+        return G
+
     def broadcast_(self, t, src=0):
         """Rank `src`'s values on every rank (start vectors drawn from a random generator)."""
         if self.world == 1:

@@ -282,13 +282,22 @@ class EngineBase:
         """Bring up to date whatever cached state the local problem of `node` will read."""
 
     # -- Gram + solve workspaces
-    def gram_ws(self, lp, H, sym):
+    def gram_ws(self, lp, H, sym, shard=None):
+        """Compressed Gram of a single-term local problem into the cached workspace.  shard: the
+        sample sharding of a multi-rank run; the feature-pair classes are then the ones common to
+        all ranks (agreed on once per feature tensor)."""
         L, X, R = lp.terms[0]
         key = (lp.S, lp.C, L.shape[2], X.shape[1], R.shape[1], int(sym))
         ws = self._gram_ws.get(key)
         if ws is None:
             self._gram_ws.clear()
-        ws = ops.gram(L, H, X, R, sym=sym, ws=ws, pair_rep=self.pair_rep(X))
+        rep = self.pair_rep(X)
+        if shard is not None:
+            ckey = ("common",) + self._pair_key(X)
+            if ckey not in self._pairs:
+                self._pairs[ckey] = shard.common_pair_classes(rep, X.shape[1] * (X.shape[1] + 1) // 2, X.device)
+            rep = self._pairs[ckey]
+        ws = ops.gram(L, H, X, R, sym=sym, ws=ws, pair_rep=rep)
         self._gram_ws[key] = ws
         return ws
 

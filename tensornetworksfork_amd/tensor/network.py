@@ -300,9 +300,9 @@ class TensorNetwork:
         front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None}
         if lp.compressed_gram(self._hessian_symmetric(H)):
             # compressed symmetric Gram in the workspace, own Cholesky on it
-            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
+            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H), shard=self._shard if d.sharded else None)
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
-                self._shard.allreduce_sum_(ws.compressed)
+                self._shard.allreduce_gram_(ws)
                 self._shard.allreduce_sum_(b)
             front["ws"] = ws
         else:

@@ -44,6 +44,20 @@ def main():
         v = torch.full((3,), float(sh.rank + 1))
         sh.broadcast_(v)
         ok &= bool(torch.equal(v, torch.ones(3)))
+        # feature-pair classes common to all ranks, and the packed all-reduce of a classed Gram
+        ok &= sh.common_pair_classes([0, 0, 0, 3] if sh.rank == 0 else [0, 0, 2, 3], 4, "cpu") == [0, 0, 2, 3]
+        ok &= sh.common_pair_classes([0, 1, 1, 3] if sh.rank == 0 else None, 4, "cpu") is None
+        ok &= sh.common_pair_classes([0, 1, 1, 1], 4, "cpu") == [0, 1, 1, 1]
+
+        class FakeWS:
+            mppad, pair_rep = 6, [0, 1, 1, 3, 0]
+        G = torch.arange(6 * 5 * 7, dtype=torch.float64).reshape(6, 5, 7) * (sh.rank + 1)
+        G[:, 2], G[:, 4] = G[:, 1], G[:, 0]          # members equal their representative, as the kernel leaves them
+        FakeWS.compressed = G.reshape(-1).clone()
+        want = FakeWS.compressed.clone()
+        sh.allreduce_sum_(want)
+        sh.allreduce_gram_(FakeWS)
+        ok &= bool(torch.equal(FakeWS.compressed, want))
     else:
         from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
         from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
@@ -72,7 +86,21 @@ def main():
                                loss_callback=lambda l: losses.append(l))
             return [n.tensor.clone() for n in tn.main_nodes], losses
 
-        for which in ("gram", "cg", "lanczos"):
+        xraw = torch.rand(S, generator=g) * 2 - 1
+        xpoly = [torch.stack([xraw ** k for k in range(4)], dim=-1).contiguous().to(dev) for _ in range(N)]
+        for which in ("gram", "gram_classed", "cg", "lanczos"):
+            if which == "gram_classed":       # powers of one variable: feature-pair classes, packed all-reduce
+                x_plain, x = x, xpoly
+                c1, l1 = run(False, "gram")
+                c2, l2 = run(True, "gram")
+                x = x_plain
+                for a, b in zip(c1, c2):
+                    ok &= ((a - b).norm() / a.norm()).item() < 1e-9
+                for t in c2:
+                    ref = t.clone()
+                    sh.broadcast_(ref)
+                    ok &= bool(torch.equal(ref, t))
+                continue
             if which == "lanczos":
                 torch.manual_seed(100)
             c1, l1 = run(False, which) if which != "lanczos" else (None, None)
