@@ -154,6 +154,11 @@ int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream
 int ttk_dot_f64(const double* x, const double* y, double* out, int64_t n, void* stream);
 int ttk_axpy_f64(const double* a, double sign, const double* x, double* y, int64_t n, void* stream);
 
+/* GL[s,l] = sum_c g[s,c] L[s,c,l]: the output index of the left environment contracted with the
+ * gradient (or with H u), the first factor of b = J^T g (get_b, tensor/network.py:258-291) when the
+ * features are contracted last (sites with many features). */
+int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, void* stream);
+
 /* The vector half of a Krylov iteration as one launch of one workgroup (the vectors have the
  * size of one core), so that an iteration is the operator product plus one more kernel and the
  * host never waits inside the loop.

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ttk_qr_f64": (_int, [_c_dp, _int, _int, _c_dp, _c_dp, _c_dp]),
     "ttk_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_axpy_f64": (_int, [_c_dp, _dbl, _c_dp, _c_dp, _i64, _c_dp]),
+    "ttk_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_cg_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _c_dp]),
 }

@@ -2533,6 +2533,13 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
   return ttk_launch_status();
 }
 
+int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, void* stream) {
+  if (!g || !L || !GL || S < 1 || C < 1 || rl < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(rhs_gl_kernel, dim3((unsigned)((S * rl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, L, GL, S,
+                     C, rl);
+  return ttk_launch_status();
+}
+
 int ttk_jvp_f64(const double* L, const double* X, const double* R, const double* H, const double* v, double* tmp,
                 double* hu, int64_t S, int C, int rl, int p, int rr, void* stream) {
   if (!L || !X || !R || !H || !v || !tmp || !hu || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;

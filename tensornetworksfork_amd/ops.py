@@ -344,3 +344,12 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
                                            _chk(betas, "betas"), int(j), w.numel(), _stream(w))
     _lib.check(rc, "ttk_lanczos_update_f64")
     return v_next
+
+
+def gl(g, L):
+    """GL (S,rl) = sum_c g[s,c] L[s,c,l]."""
+    S, C, rl = L.shape
+    out = torch.empty((S, rl), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_gl_f64(_chk(g, "g", (S, C)), _chk(L, "L"), out.data_ptr(), S, C, rl, _stream(L))
+    _lib.check(rc, "ttk_gl_f64")
+    return out

@@ -122,6 +122,19 @@ def _xt_times(X, W, chunk=1024):
 TWO_STAGE_MIN_P = 16    # from this many features on, J v and J^T g contract the features first (library GEMM)
 
 
+_ONES = {}
+
+
+def _ones_col(S, device):
+    """(S,1) column of ones (a feature factor that contributes nothing), cached per size and device."""
+    key = (S, str(device))
+    if key not in _ONES:
+        if len(_ONES) > 8:
+            _ONES.clear()
+        _ONES[key] = torch.ones((S, 1), dtype=F64, device=device)
+    return _ONES[key]
+
+
 class LocalProblem:
     """The normal equations of one train node for a bound data set.
 
@@ -159,8 +172,8 @@ class LocalProblem:
             if X.shape[1] >= TWO_STAGE_MIN_P:
                 # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L : one plain GEMM over the samples
                 S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
-                GL = (g.unsqueeze(2) * L).sum(dim=1)                                     # (S, rl)
-                W = (GL.unsqueeze(2) * R.unsqueeze(1)).reshape(S, rl * rr)
+                GL = ops.gl(g, L)                                                        # (S, rl)
+                W = ops.kr_rows(GL.unsqueeze(1), _ones_col(S, g.device), R).reshape(S, rl * rr)   # GL[s,l] R[s,r]
                 bt = _xt_times(X, W).reshape(X.shape[1], rl, rr).permute(1, 0, 2)
                 out = bt.contiguous() if out is None else out.add_(bt)
             else:
@@ -180,9 +193,8 @@ class LocalProblem:
                 # the C outputs of a sample), then the two environments: C*p/(C+p) times fewer FLOPs
                 S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
                 T = X @ v.permute(1, 0, 2).reshape(X.shape[1], rl * rr)                 # (S, rl*rr)
-                z = (T.reshape(S, rl, rr) * R.unsqueeze(1)).sum(dim=2)                   # (S, rl)
-                t = (L * z.unsqueeze(1)).sum(dim=2)                                      # (S, C)
-                u = t if u is None else u.add_(t)
+                z = ops.predict(T.reshape(S, rl, rr), R)                                 # (S, rl)
+                u = ops.predict(L, z) if u is None else ops.predict(L, z, out=u)         # (S, C)
                 continue
             key = id(R)                  # terms that share R share one environment-step buffer
             if key in tmp:
@@ -636,8 +648,8 @@ class ChainEngine(EngineBase):
                     o = None
                     for b in range(cb):
                         if two_stage:
-                            t = ((G[a, b] @ cm).reshape(-1, rl, rr) * Rn[b].unsqueeze(1)).sum(dim=2)
-                            o = t if o is None else o.add_(t)
+                            T = (G[a, b] @ cm).reshape(-1, rl, rr)
+                            o = ops.predict(T, Rn[b]) if o is None else ops.predict(T, Rn[b], out=o)
                         else:
                             o = ops.env_step_right(Rn[b], G[a, b], core) if o is None else \
                                 ops.env_step_right(Rn[b], G[a, b], core, out=o)
