@@ -166,8 +166,20 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   double* Ew = tiles + wave * (e + p) * 17;
   double* Xw = Ew + e * 17;
-  auto swz = [](int k) { return ((k >> 1) & 15) | (SW ? ((k & 1) << 4) : 0); };
-  if (LEFT) {   // core (e, p, n) = [K][n]: lanes along a row, eight rows in flight per thread
+  // only the right-hand step permutes (its transposing store needs it); 16 lanes are served per
+  // LDS cycle, so the MFMA operand reads of a plain row-major core are conflict free as they are
+  auto swz = [](int k) { return LEFT ? 0 : (((k >> 1) & 15) | (SW ? ((k & 1) << 4) : 0)); };
+  const bool dma = LEFT && n == npad && ((K * npad) & 127) == 0;
+  if (dma) {
+    // the core is the LDS image as it stands: copied by global_load_lds (1 KiB per wave instruction,
+    // everything in flight at once, no registers), rows K..Kp zeroed beside it
+    const int units = (K * npad) >> 1;
+    for (int it = wave; it * 64 < units; it += 4)
+      __builtin_amdgcn_global_load_lds(
+          (const void __attribute__((address_space(1)))*)((const char*)core + (size_t)(it * 64 + lane) * 16),
+          (void __attribute__((address_space(3)))*)((char*)Bs + it * 1024), 16, 0, 0);
+    for (int idx = K * npad + tid; idx < Kp * npad; idx += 256) Bs[idx] = 0.0;
+  } else if (LEFT) {   // core (e, p, n) = [K][n]: lanes along a row, eight rows in flight per thread
     constexpr int RPP = 256 / npad;
     const int jj = tid % npad, kk = tid / npad;
     const bool on = kk < RPP;
@@ -243,9 +255,10 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
     }
   };
   if (tile < ntiles) fetch(tile);
+  if (dma) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of the core has landed
   __syncthreads();
   const int ib = i ^ (kq >> 1);                          // low swizzle bits that depend on the lane only
-  const int par = SW ? (kq & 1) : 0;
+  const int par = (SW && !LEFT) ? (kq & 1) : 0;
   // Results leave one tile late (DEFER): a wave's stores and its prefetch loads retire in issue order,
   // so stores issued right before the next tile's loads would be waited for together with them;
   // issued a whole tile earlier they have long completed.  Costs NT*8 registers, so only for NT <= 2.
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
       for (int u = 0; u < 4; ++u) {
         ev[u] = Ew[(o[u] & 0xffff) + i];
         xv[u] = Xw[(o[u] >> 16) + i];
-        const double* brow = Bs + min(g * 16 + u * 4 + kq, Kp - 1) * npad + (ib ^ (2 * u + 8 * odd));
+        const double* brow = Bs + min(g * 16 + u * 4 + kq, Kp - 1) * npad + (LEFT ? i : (ib ^ (2 * u + 8 * odd)));
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[u][j] = brow[(j ^ par) << 4];
       }
