@@ -144,10 +144,9 @@ __global__ __launch_bounds__(256, 2) void env_step_kernel(const double* __restri
 // left operand E[row,ei] * X[row,pi] is formed per lane from a (ei, pi) offset table.
 // mode 0: out[row, :] (+)= result;  mode 1: out[row] (+)= <result row, Rdot[row / C, :]> [* Hmul[row]]  (J v).
 //
-// Core rows in LDS are column-permuted: element (k, j) sits at column j ^ swz(k).  Bits 0-3 of
-// swz spread a column of the core over all banks (the right-hand step stores it that way, lanes
-// along k); bit 4, used when a row spans a whole number of bank wraps, keeps the four k rows of
-// one MFMA operand off each other's banks.
+// For the right-hand step the core rows in LDS are column-permuted: element (k, j) sits at column
+// j ^ swz(k), which spreads a column of the core over all banks (that step stores the core
+// transposed, lanes along k).  The left-hand step keeps the core exactly as it is in memory.
 #define ENVF_SLOTS 12   // prefetch registers per lane: ceil(e / 4) + ceil(p / 4) of them are used
 template <bool LEFT, int NT>
 __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restrict__ E, const double* __restrict__ X,
