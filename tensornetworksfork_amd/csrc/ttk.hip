@@ -391,6 +391,178 @@ __global__ __launch_bounds__(256, 2) void env_fast_kernel(const double* __restri
   if (DEFER && hold_row0 >= 0) flush(hold, hold_row0);
 }
 
+// The same step for bond dimensions e = 4 * E4 (16 or 32) and at most 8 features, without any
+// per-tile staging: lane (i, kq) of a wave owns row i of its 16-row tile and keeps the entries
+// E[row, 4 t + kq] (t < E4) and X[row, :] in registers, fetched straight from memory (the next
+// tile's while the current one is multiplied).  With the contraction ordered as (feature, t) the
+// MFMA operand of a step is er[t] * xr[feature]: one multiply, no LDS read, no offset table; only
+// the core rows come from LDS.  Core staging, epilogues and modes as in env_fast_kernel.
+template <bool LEFT, int NT, int E4>
+__global__ __launch_bounds__(256, 2) void env_reg_kernel(const double* __restrict__ E, const double* __restrict__ X,
+                                                          const double* __restrict__ core, double* __restrict__ out,
+                                                          int Mi, int C, int p, int n, int accumulate, int mode,
+                                                          const double* __restrict__ Rdot,
+                                                          const double* __restrict__ Hmul) {
+  extern __shared__ double smem[];
+  constexpr int npad = NT * 16;
+  constexpr int SW = (NT % 2 == 0) ? 1 : 0;
+  constexpr int e = 4 * E4;
+  const int K = e * p;                                 // a multiple of 4: no padded rows
+  double* Bs = smem;                                   // [K][npad]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  auto swz = [](int k) { return LEFT ? 0 : (((k >> 1) & 15) | (SW ? ((k & 1) << 4) : 0)); };
+  const bool dma = LEFT && n == npad && ((K * npad) & 127) == 0;
+  if (dma) {
+    const int units = (K * npad) >> 1;
+    for (int it = wave; it * 64 < units; it += 4)
+      __builtin_amdgcn_global_load_lds(
+          (const void __attribute__((address_space(1)))*)((const char*)core + (size_t)(it * 64 + lane) * 16),
+          (void __attribute__((address_space(3)))*)((char*)Bs + it * 1024), 16, 0, 0);
+  } else if (LEFT) {   // core (e, p, n) = [K][n]
+    constexpr int RPP = 256 / npad;
+    const int jj = tid % npad, kk = tid / npad;
+    const bool on = kk < RPP;
+    for (int k0 = kk; k0 < K; k0 += RPP * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = core[min(k0 + u * RPP, K - 1) * n + min(jj, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * RPP;
+        if (on && k < K) Bs[k * npad + jj] = jj < n ? v[u] : 0.0;
+      }
+    }
+  } else {             // core (n, p, e) = [n][K], stored transposed and column-permuted
+    for (int k = tid; k < K; k += 256) {
+      const int sz = swz(k);
+#pragma unroll
+      for (int j0 = 0; j0 < npad; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = core[min(j0 + u, n - 1) * K + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Bs[k * npad + ((j0 + u) ^ sz)] = (j0 + u < n) ? v[u] : 0.0;
+      }
+    }
+  }
+  const int ntiles = (Mi + 15) >> 4;
+  const int stride = (int)gridDim.x * 4;
+  int tile = (int)blockIdx.x * 4 + wave;
+  double er[E4], xr[8], ern[E4], xrn[8];
+  // unconditional loads with clamped indices (features past p repeat the last one and are never used)
+  auto fetch = [&](int t, double (&ev)[E4], double (&xv)[8]) {
+    const int row = min((t << 4) + i, Mi - 1);
+    const double* es = E + row * e + kq;
+    const double* xs = X + (C == 1 ? row : row / C) * p;
+#pragma unroll
+    for (int u = 0; u < E4; ++u) ev[u] = es[4 * u];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xv[q] = xs[min(q, p - 1)];
+  };
+  if (tile < ntiles) fetch(tile, ern, xrn);
+  if (dma) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of the core has landed
+  __syncthreads();
+  // lane part of the core row address of a step: LEFT row (4 t + kq) p + feature, else feature e + 4 t + kq
+  const int lane_row = LEFT ? kq * p : kq;
+  constexpr bool DEFER = NT <= 2;
+  d4 hold[NT];
+  int hold_row0 = -1;
+  auto flush = [&](const d4 (&v)[NT], int row0) {
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = row0 + kq + 4 * t;
+          const int col = j * 16 + i;
+          if (row < Mi && col < n) {
+            double* o = out + (int64_t)row * n + col;
+            *o = accumulate ? *o + v[j][t] : v[j][t];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = row0 + kq + 4 * t;
+        if (i == 0 && row < Mi) out[row] = accumulate ? out[row] + v[0][t] : v[0][t];
+      }
+    }
+  };
+  for (; tile < ntiles; tile += stride) {
+    const int row0 = tile << 4;
+#pragma unroll
+    for (int u = 0; u < E4; ++u) er[u] = ern[u];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xr[q] = xrn[q];
+    if (DEFER && hold_row0 >= 0) flush(hold, hold_row0);
+    if (tile + stride < ntiles) fetch(tile + stride, ern, xrn);
+    double rv[DEFER ? 4 : 1][NT], hv[DEFER ? 4 : 1];
+    if (DEFER && mode != 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rc = min(row0 + kq + 4 * t, Mi - 1);
+        const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[t][j] = rp[min(j * 16 + i, n - 1)];
+        hv[t] = Hmul ? Hmul[rc] : 1.0;
+      }
+    }
+    d4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < p) {   // uniform; E4 steps of straight-line code per feature
+#pragma unroll
+        for (int u = 0; u < E4; ++u) {
+          const int krow = (LEFT ? 4 * u * p + q : q * e + 4 * u) + lane_row;
+          const double a = er[u] * xr[q];
+          const double* brow = Bs + krow * npad + i;
+          if (LEFT) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, brow[j * 16], acc[j]);
+          } else {
+            const int sz = swz(krow);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, Bs[krow * npad + ((j * 16 + i) ^ sz)], acc[j]);
+          }
+        }
+      }
+    }
+    if (mode != 0) {   // row dot products; the result of row kq + 4 t lands in acc[0][t] of the lanes i == 0
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        double u = 0.0, h;
+        if (DEFER) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rv[t][j] : 0.0;
+          h = hv[t];
+        } else {
+          const int rc = min(row0 + kq + 4 * t, Mi - 1);
+          const double* rp = Rdot + (int64_t)(C == 1 ? rc : rc / C) * n;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) u += (j * 16 + i < n) ? acc[j][t] * rp[min(j * 16 + i, n - 1)] : 0.0;
+          h = Hmul ? Hmul[rc] : 1.0;
+        }
+        u += __shfl_xor(u, 8, 16);
+        u += __shfl_xor(u, 4, 16);
+        u += __shfl_xor(u, 2, 16);
+        u += __shfl_xor(u, 1, 16);
+        acc[0][t] = u * h;
+      }
+    }
+    if (DEFER) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) hold[j] = acc[j];
+      hold_row0 = row0;
+    } else {
+      flush(acc, row0);
+    }
+  }
+  if (DEFER && hold_row0 >= 0) flush(hold, hold_row0);
+}
+
 static bool env_fast_ok(int e, int p, int n, size_t* lds) {
   const int K = e * p, npad = (n + 15) & ~15;
   const int Kp = (K + 15) & ~15;
@@ -398,6 +570,8 @@ static bool env_fast_ok(int e, int p, int n, size_t* lds) {
   *lds = bytes;
   return npad <= 64 && (e + 3) / 4 + (p + 3) / 4 <= ENVF_SLOTS && bytes <= 80 * 1024 && e * 17 < 65536 && p * 17 < 32768;
 }
+
+static int g_env_reg = 1;   // 0: the register-operand variant is not used (experiments)
 
 // Launches the resident-core kernel when the shape allows it; returns 1 when it does not (nothing launched).
 static int env_fast_launch(bool left, const double* E, const double* X, const double* core, double* out, int64_t M,
@@ -408,6 +582,33 @@ static int env_fast_launch(bool left, const double* E, const double* X, const do
   const int64_t ntiles = (M + 15) >> 4;
   const unsigned grid = (unsigned)((ntiles + 3) / 4 < 512 ? (ntiles + 3) / 4 : 512);
   const int nt = (n + 15) >> 4;
+  if ((e == 16 || e == 32) && p <= 8 && g_env_reg && !(!left && nt == 4 && e == 32)) {   // (that one variant spills)
+    const void* regv[16] = {
+        (const void*)env_reg_kernel<true, 1, 4>,  (const void*)env_reg_kernel<true, 2, 4>,
+        (const void*)env_reg_kernel<true, 3, 4>,  (const void*)env_reg_kernel<true, 4, 4>,
+        (const void*)env_reg_kernel<true, 1, 8>,  (const void*)env_reg_kernel<true, 2, 8>,
+        (const void*)env_reg_kernel<true, 3, 8>,  (const void*)env_reg_kernel<true, 4, 8>,
+        (const void*)env_reg_kernel<false, 1, 4>, (const void*)env_reg_kernel<false, 2, 4>,
+        (const void*)env_reg_kernel<false, 3, 4>, (const void*)env_reg_kernel<false, 4, 4>,
+        (const void*)env_reg_kernel<false, 1, 8>, (const void*)env_reg_kernel<false, 2, 8>,
+        (const void*)env_reg_kernel<false, 3, 8>, (const void*)env_reg_kernel<false, 4, 8>};
+    static bool reg_lds_set = false;
+    if (!reg_lds_set) {
+      for (int v = 0; v < 16; ++v)
+        if (hipFuncSetAttribute(regv[v], hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+          return TTK_ELAUNCH;
+      reg_lds_set = true;
+    }
+    const size_t rlds = (size_t)e * p * (nt * 16) * sizeof(double);   // <= 32 * 8 * 64 * 8 = 128 KiB ... checked below
+    if (rlds <= 80 * 1024) {
+      int Mi = (int)M;
+      void* args[] = {(void*)&E, (void*)&X, (void*)&core, (void*)&out, (void*)&Mi, (void*)&C, (void*)&p, (void*)&n,
+                      (void*)&accumulate, (void*)&mode, (void*)&Rdot, (void*)&Hmul};
+      const void* fn = regv[(left ? 0 : 8) + (e == 32 ? 4 : 0) + nt - 1];
+      if (hipLaunchKernel(fn, dim3(grid), dim3(256), args, rlds, st) != hipSuccess) return TTK_ELAUNCH;
+      return ttk_launch_status();
+    }
+  }
   static bool big_lds_set = false;   // dynamic LDS above 64 KiB has to be allowed once per kernel
   const void* variants[8] = {(const void*)env_fast_kernel<true, 1>,  (const void*)env_fast_kernel<true, 2>,
                              (const void*)env_fast_kernel<true, 3>,  (const void*)env_fast_kernel<true, 4>,
@@ -2457,6 +2658,7 @@ int ttk_debug_syrk_tile(int ts) { g_syrk_tile = ts; return 0; }
 int ttk_debug_group(int g) { g_group4_min = g; return 0; }
 int ttk_debug_rhs_slabs(int n) { g_rhs_max_slabs = n; return 0; }
 int ttk_debug_gram_slabs(int n) { g_gram_slabs = n; return 0; }
+int ttk_debug_env_reg(int on) { g_env_reg = on; return 0; }
 int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
 #endif
 

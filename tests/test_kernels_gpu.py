@@ -24,6 +24,8 @@ SHAPES = [  # S, C, rl, p, rr
     (200, 2, 7, 5, 9), (1, 1, 3, 2, 3), (300, 1, 24, 50, 24), (100, 9, 9, 17, 20), (257, 1, 48, 5, 70),
     # many ragged 16-row tiles per wave of the resident-core kernel, 1..4 column tiles
     (5000, 3, 8, 3, 40), (40999, 1, 8, 4, 64), (2001, 2, 16, 2, 17), (70001, 1, 32, 6, 32), (9000, 1, 40, 3, 8),
+    # bonds of 16 / 32 with at most 8 features: operands held in registers, both directions, 1..4 column tiles
+    (4099, 3, 16, 8, 48), (3001, 2, 32, 5, 16), (1500, 1, 64, 3, 32), (2500, 1, 16, 7, 32), (777, 1, 32, 8, 16),
 ]
 
 
