@@ -1111,18 +1111,23 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const double* __
   }
 }
 
-// Slab reduction of a classed Gram: slice b of the result is the sum over slabs of the slice of
-// its representative (with one slab and partial == out this only replicates, in place: a
-// representative's slice is rewritten with its own value).
+// Slab reduction of a classed Gram: one thread per element of a representative slice adds the
+// slabs once and stores the sum into the slice of every member of the class (with one slab and
+// partial == out this only replicates, in place).
 __global__ __launch_bounds__(256) void gram_reduce_classed_kernel(const double* __restrict__ partial, int nslabs,
                                                                    int64_t stride, GramDims gd, double* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= gd.gsize) return;
-  const int b = (int)((idx / gd.NRpad) % gd.NX);
-  const int64_t src = idx + (int64_t)(gd.repof[b] - b) * gd.NRpad;
+  if (idx >= (int64_t)gd.MPpad * gd.nrep * gd.NRpad) return;
+  const int c = (int)(idx % gd.NRpad);
+  const int64_t ak = idx / gd.NRpad;
+  const int k = (int)(ak % gd.nrep);
+  const int64_t a = ak / gd.nrep;
+  const int b0 = gd.reps[k];
+  const int64_t src = (a * gd.NX + b0) * gd.NRpad + c;
   double acc = 0.0;
-  for (int k = 0; k < nslabs; ++k) acc += partial[(int64_t)k * stride + src];
-  out[idx] = acc;
+  for (int s_ = 0; s_ < nslabs; ++s_) acc += partial[(int64_t)s_ * stride + src];
+  for (int b = b0; b < gd.NX; ++b)   // members come after their representative
+    if (gd.repof[b] == b0) out[(a * gd.NX + b) * gd.NRpad + c] = acc;
 }
 
 __global__ __launch_bounds__(1024) void gram_scale_kernel(const double* __restrict__ G, int rl, int p, int rr, int sym,
@@ -2572,7 +2577,8 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.classed) {
-    hipLaunchKernelGGL(gram_reduce_classed_kernel, dim3((unsigned)((d.gsize + 255) / 256)), dim3(256), 0, st,
+    const int64_t nred = (int64_t)d.MPpad * d.nrep * d.NRpad;
+    hipLaunchKernelGGL(gram_reduce_classed_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st,
                        (const double*)partial, d.nslabs, d.gsize, d, G);
     rc = ttk_launch_status();
   } else if (d.nslabs > 1) {
