@@ -119,6 +119,7 @@ def _xt_times(X, W, chunk=1024):
     return out
 
 
+DENSE_ROWS_KERNEL_MAX_D = 128   # explicit Jacobian rows up to this width go through the Khatri-Rao kernels
 TWO_STAGE_MIN_P = 16    # from this many features on, J v and J^T g contract the features first (library GEMM)
 
 
@@ -164,8 +165,11 @@ class LocalProblem:
     def rhs(self, g):
         """b = J^T g, canonical shape."""
         if self.J is not None:
-            # a few dozen columns against half a million rows: element-wise product + row sums run at
-            # memory speed, the library's matrix-vector kernels do not
+            if self.D <= DENSE_ROWS_KERNEL_MAX_D:
+                # explicit rows are a Khatri-Rao term with the rows as left factor and no other factor
+                one = _ones_col(self.S, g.device)
+                return ops.rhs(self.J.contiguous(), one, one, g.reshape(self.S, self.C).contiguous()).reshape(self.shape)
+            # wide rows: element-wise product + row sums (the library's tall-skinny matrix-vector kernels are slow)
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
         for (L, X, R) in self.terms:
@@ -183,6 +187,9 @@ class LocalProblem:
     def jv(self, v):
         """u[s,c] = J v."""
         if self.J is not None:
+            if self.D <= DENSE_ROWS_KERNEL_MAX_D:
+                one = _ones_col(self.S, v.device)
+                return ops.env_step_left(self.J.contiguous(), one, v.reshape(self.D, 1, 1).contiguous()).reshape(self.S, self.C)
             return (self._jt() * v.reshape(self.D, 1)).sum(dim=0).reshape(self.S, self.C)
         v = v.reshape(self.shape)
         u = None
