@@ -202,6 +202,11 @@ def gram_expand(ws, scale=None, ridge=0.0, out=None):
 _rhs_ws = {}
 
 
+def rhs_supported(S, C, rl, p, rr):
+    """Whether ttk_rhs_f64 accepts these extents (a chunk of its sample rows must fit LDS)."""
+    return int(_lib.lib().ttk_rhs_ws_bytes(int(S), int(C), int(rl), int(p), int(rr))) > 0
+
+
 def rhs(L, X, R, g, out=None):
     """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r]; with `out` given the result is added to it."""
     S, C, rl = L.shape
