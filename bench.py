@@ -110,33 +110,98 @@ def cg_variant(device, F, y, steps):
                                    "hbm_frac_lower_bound": 101 * it_bytes / per * 1e-9 / HBM_PEAK_GBS}}
 
 
-def cpu_baseline(sample=54000, sites=(6, 7, 8)):
-    """The CPU oracle on the host cores: environments + Gram/RHS + ridge_cholesky solve of middle
-    sites (D=6144) on `sample` of the 54 000 training samples (linear extrapolation in the sample
-    count when fewer), averaged over `sites`."""
+def parity_and_cpu_baseline(device, F, y, sites=(6, 7, 8), eps=1.0):
+    """ONE problem, two paths.  For each of `sites` (middle sites, D = 6144) the core update of the
+    timed workload - same features, targets, cores after orthonormalize_left, ridge - is computed by
+    the CPU oracle (environments from scratch, Gram + RHS over all 54 000 samples, scaled
+    ridge_cholesky solve, core update: tensor/network.py:174-217,293-327 as models/tnml.py:218-234
+    drives them) and by the HIP path through the public API, both starting from the same cores.
+    Returns (parity, cpu_baseline): relative Frobenius errors of loss, b, A, step and updated core
+    (worst site), and the oracle's timing on the host cores."""
     from oracle import tt_oracle as O
-    rng = np.random.RandomState(0)
-    X = torch.tensor(rng.uniform(-1, 1, (sample, N_FEAT)))
-    y = torch.tensor(np.sin(X.numpy()).sum(1, keepdims=True))
-    xs = O.polynomial_basis(X, DEGREE)
-    cores = O.init_tt_cores(N_SITES, BOND, DEGREE + 1, 1, True, seed=42, dtype=torch.float64)
-    S_train = int(S_ALL * 0.9)
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    layer = make_model(device)
+    tn = layer.tensor_network
+    nodes = tn.main_nodes
+    cores0 = [n.tensor.detach().clone() for n in nodes]
+    cores_cpu = [c.cpu() for c in cores0]
+    xs_cpu = [f.cpu() for f in F]
+    y_cpu = y.cpu()
+    S_train = xs_cpu[0].shape[0]
+    bf = SquareBregFunction()
+
+    def rel(a, ref):
+        ref = ref.to(a.device)
+        return float(((a - ref).norm() / ref.norm()).item())
+
+    worst = {"loss_rel_err": 0.0, "b_rel_err": 0.0, "A_rel_err": 0.0, "step_rel_err": 0.0, "core_rel_err": 0.0}
     t_gram = t_solve = 0.0
+    step_norm = 0.0
     for k in sites:
         t0 = time.perf_counter()
-        A, b, loss, g, H = O.site_problem(cores, xs, k, y, 'square')
-        t_gram += time.perf_counter() - t0
+        A, b, loss, g, H = O.site_problem(cores_cpu, xs_cpu, k, y_cpu, 'square')
+        t1 = time.perf_counter()
+        step = O.solve_system(A, b, O.canon(cores_cpu)[k], 'ridge_cholesky', eps)
+        new_core = O.update_core(cores_cpu[k], step.reshape(cores_cpu[k].shape))
+        t2 = time.perf_counter()
+        t_gram += t1 - t0
+        t_solve += t2 - t1
+        step_norm = float(step.norm())
+        for n, c in zip(nodes, cores0):
+            n.tensor = c.clone()
+        node = nodes[k]
+        y_pred = tn.forward(F, to_tensor=True)
+        _, gh, Hh = bf.forward(y_pred, y)
+        A_h, b_h = tn.get_A_b(node, gh, Hh)
+        errs = {"b_rel_err": rel(b_h.reshape(-1), b.reshape(-1)), "A_rel_err": rel(A_h.reshape(-1), A.reshape(-1))}
+        del A_h, A
+        losses = []
+        ok = tn.accumulating_swipe(F, y, bf, node_order=([node], []), batch_size=-1, lr=1.0, eps=eps,
+                                   method='ridge_cholesky', skip_second=True, num_swipes=1,
+                                   loss_callback=lambda NS, n, l: losses.append(l))
+        assert ok and len(losses) == 1
+        errs["loss_rel_err"] = abs(losses[0] - float(loss)) / abs(float(loss))
+        errs["step_rel_err"] = rel((node.tensor - cores0[k]).reshape(-1), step.reshape(-1))
+        errs["core_rel_err"] = rel(node.tensor.reshape(-1), new_core.reshape(-1))
+        for key, v in errs.items():
+            worst[key] = max(worst[key], v)
+    n = len(sites)
+    per = (t_gram + t_solve) / n
+    parity = dict(worst)
+    parity.update({"sites": list(sites), "eps": eps, "tolerance": 1e-5,
+                   "ok": bool(max(worst.values()) <= 1e-5),
+                   "what": "worst relative Frobenius error over the sites; HIP path vs CPU oracle on identical inputs"})
+    cpu = {"value": 1.0 / per, "unit": "core-updates/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"oracle environments + Gram + RHS on all {S_train} samples ({t_gram / n:.2f} s) + D=6144 "
+                     f"ridge_cholesky solve + core update ({t_solve / n:.2f} s), mean of {n} middle sites of the timed "
+                     f"problem ({t_gram + t_solve:.1f} s of CPU work); the same updates are the parity check",
+           "samples_per_sec": S_train / per, "step_norm": step_norm}
+    return parity, cpu
+
+
+def sweep_variant(device, F, y, F_val, y_val, repeats=3):
+    """Whole first swipes of TNMLRegressor.fit's call (31 core updates: every site left to right, then
+    back, edge sites included, validation pass after every update), each from a fresh model."""
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    times, updates = [], 0
+    for rep in range(repeats + 1):
+        layer = make_model(device)
+        tn = layer.tensor_network
+        hook = StepCounter(tn, F_val, y_val, 10 ** 9)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        step = O.solve_system(A, b, O.canon(cores)[k], 'ridge_cholesky', 1.0)
-        t_solve += time.perf_counter() - t0
-    t_gram /= len(sites)
-    t_solve /= len(sites)
-    per = t_gram * (S_train / sample) + t_solve
-    return {"value": 1.0 / per, "unit": "core-updates/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle envs+Gram+RHS on {sample} of {S_train} samples ({t_gram:.2f} s, scaled x{S_train / sample:.2f}) "
-                      f"+ full D=6144 ridge_cholesky solve ({t_solve:.2f} s), mean of {len(sites)} middle sites "
-                      f"({(t_gram + t_solve) * len(sites):.1f} s of CPU work)",
-            "samples_per_sec": S_train / per, "step_norm": float(step.norm())}
+        ok = tn.accumulating_swipe(F, y, SquareBregFunction(), batch_size=512, lr=1.0, eps=1.0, eps_decay=0.5,
+                                   convergence_criterion=hook, orthonormalize=True, method='ridge_cholesky',
+                                   num_swipes=1, direction='l2r')
+        torch.cuda.synchronize()
+        if rep:      # the first one warms caches and workspaces up
+            times.append(time.perf_counter() - t0)
+        updates = hook.count
+        assert ok
+    t = float(np.mean(times))
+    S = F[0].shape[0]
+    return {"updates_per_sweep": updates, "sweep_ms": t * 1e3, "core_updates_per_sec": updates / t,
+            "samples_per_sec_sweep": S / t, "repeats": repeats, "val_rmse": hook.last}
 
 
 def main():
@@ -146,7 +211,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=54000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,9 +297,10 @@ def main():
                      "dense_equivalent_tflops": 2.0 * S_local * D * D / (avg_ms * 1e-3) * 1e-12},
     }
     if rank == 0 and world == 1 and not args.no_variants:
-        out["variants"] = {"cg": cg_variant(device, F, y, steps=4)}
+        out["variants"] = {"cg": cg_variant(device, F, y, steps=10),
+                           "sweep": sweep_variant(device, F, y, F_val, y_val)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        out["parity"], out["cpu_baseline"] = parity_and_cpu_baseline(device, F, y)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -233,34 +233,53 @@ def jacobian(Lenv, X, Renv):
     return torch.einsum('scl,sp,sr->sclpr', Lenv, X, Renv)
 
 
+def _sample_chunks(S, C, D, budget_bytes=1 << 30):
+    """Sample ranges whose explicit Jacobian rows (C*D doubles per sample) stay below the budget:
+    sums over samples are taken chunk by chunk so that large sites fit in host memory."""
+    step = max(1, int(budget_bytes // (8 * C * D)))
+    return [(lo, min(S, lo + step)) for lo in range(0, S, step)]
+
+
 def local_gram_rhs(Lenv, X, Renv, g, H):
     """A[lpr,mqt] = sum_{s,c,d} H[s,c,d] J[s,c,lpr] J[s,d,mqt];
-    b[lpr] = sum_{s,c} g[s,c] J[s,c,lpr].  Evaluated as two GEMMs per call,
+    b[lpr] = sum_{s,c} g[s,c] J[s,c,lpr].  Evaluated as two GEMMs per sample chunk,
     not through the reference's (S, D, D) temporary."""
     S, C, rl = Lenv.shape
     p, rr = X.shape[1], Renv.shape[1]
     D = rl * p * rr
-    J = jacobian(Lenv, X, Renv).reshape(S, C, D)
-    HJ = torch.einsum('scd,sdk->sck', H, J)
-    A = J.reshape(S * C, D).T @ HJ.reshape(S * C, D)
-    b = J.reshape(S * C, D).T @ g.reshape(S * C)
+    A = torch.zeros(D, D, dtype=Lenv.dtype)
+    b = torch.zeros(D, dtype=Lenv.dtype)
+    for lo, hi in _sample_chunks(S, C, D):
+        n = hi - lo
+        J = jacobian(Lenv[lo:hi], X[lo:hi], Renv[lo:hi]).reshape(n, C, D)
+        HJ = torch.einsum('scd,sdk->sck', H[lo:hi], J)
+        A.addmm_(J.reshape(n * C, D).T, HJ.reshape(n * C, D))
+        b.add_(J.reshape(n * C, D).T @ g[lo:hi].reshape(n * C))
     return A.reshape(rl, p, rr, rl, p, rr), b.reshape(rl, p, rr)
 
 
 def local_rhs(Lenv, X, Renv, g):
     S, C, rl = Lenv.shape
-    J = jacobian(Lenv, X, Renv).reshape(S * C, -1)
-    return (J.T @ g.reshape(S * C)).reshape(rl, X.shape[1], Renv.shape[1])
+    D = rl * X.shape[1] * Renv.shape[1]
+    b = torch.zeros(D, dtype=Lenv.dtype)
+    for lo, hi in _sample_chunks(S, C, D):
+        J = jacobian(Lenv[lo:hi], X[lo:hi], Renv[lo:hi]).reshape((hi - lo) * C, D)
+        b.add_(J.T @ g[lo:hi].reshape((hi - lo) * C))
+    return b.reshape(rl, X.shape[1], Renv.shape[1])
 
 
 def local_matvec(Lenv, X, Renv, H, v):
     """(A v)[lpr] = sum_{s,c} J[s,c,lpr] u[s,c],
     u[s,d] = sum_c H[s,c,d] sum_{lpr} J[s,c,lpr] v[lpr]  (network.py:788-789)."""
     S, C, rl = Lenv.shape
-    J = jacobian(Lenv, X, Renv).reshape(S, C, -1)
-    Jv = J @ v.reshape(-1)
-    u = torch.einsum('scd,sc->sd', H, Jv)
-    return torch.einsum('sck,sc->k', J, u).reshape(rl, X.shape[1], Renv.shape[1])
+    D = rl * X.shape[1] * Renv.shape[1]
+    out = torch.zeros(D, dtype=Lenv.dtype)
+    for lo, hi in _sample_chunks(S, C, D):
+        J = jacobian(Lenv[lo:hi], X[lo:hi], Renv[lo:hi]).reshape(hi - lo, C, D)
+        Jv = J @ v.reshape(-1)
+        u = torch.einsum('scd,sc->sd', H[lo:hi], Jv)
+        out.add_(torch.einsum('sck,sc->k', J, u))
+    return out.reshape(rl, X.shape[1], Renv.shape[1])
 
 
 # --------------------------------------------------------------------------

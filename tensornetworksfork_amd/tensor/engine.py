@@ -271,6 +271,9 @@ class LocalProblem:
         return A
 
 
+_MISSING = object()
+
+
 class EngineBase:
     """Shared plumbing of the engines behind TensorNetwork: data-set cache and solver workspaces."""
 
@@ -292,7 +295,8 @@ class EngineBase:
         d = self.make_data(raw, shard)
         self.datasets.append(d)
         if len(self.datasets) > 3:
-            self.datasets.pop(0)
+            gone = self.datasets.pop(0)
+            self.drop_pairs(getattr(gone, "xs", ()))
         return d
 
     def output_at(self, d, node, lp, core=None, rows=None):
@@ -315,38 +319,61 @@ class EngineBase:
             self._gram_ws.clear()
         rep = self.pair_rep(X)
         if shard is not None:
-            ckey = ("common",) + self._pair_key(X)
-            if ckey not in self._pairs:
-                self._pairs[ckey] = shard.common_pair_classes(rep, X.shape[1] * (X.shape[1] + 1) // 2, X.device)
-            rep = self._pairs[ckey]
+            rep = self._pair_lookup(X, "common")
+            if rep is _MISSING:
+                rep = shard.common_pair_classes(self.pair_rep(X), X.shape[1] * (X.shape[1] + 1) // 2, X.device)
+                self._pair_store(X, "common", rep)
         ws = ops.gram(L, H, X, R, sym=sym, ws=ws, pair_rep=rep)
         self._gram_ws[key] = ws
         return ws
 
+    # Feature-pair classes are cached per feature TENSOR: an entry holds the tensor that owns the
+    # memory (the base of a view), so that its address cannot be handed to another tensor while the
+    # entry lives, and the version it was computed for; a hit needs the same owner object, the same
+    # window into it and the same version (views share their base's version counter).
     @staticmethod
-    def _pair_key(X):
-        return (X.data_ptr(), tuple(X.shape), X._version)
+    def _pair_key(X, kind):
+        owner = X._base if X._base is not None else X
+        return owner, (id(owner), X.storage_offset(), tuple(X.shape), tuple(X.stride()), kind)
+
+    def _pair_lookup(self, X, kind):
+        owner, key = self._pair_key(X, kind)
+        e = self._pairs.get(key)
+        if e is not None and e[0] is owner and e[1] == X._version:
+            return e[2]
+        return _MISSING
+
+    def _pair_store(self, X, kind, rep):
+        if len(self._pairs) > 256:
+            self._pairs.clear()
+        owner, key = self._pair_key(X, kind)
+        self._pairs[key] = (owner, X._version, rep)
+
+    def drop_pairs(self, tensors):
+        """Forget the classes of feature tensors that leave the data-set cache."""
+        ids = {id(t._base if t._base is not None else t) for t in tensors}
+        for key in [k for k in self._pairs if k[0] in ids]:
+            del self._pairs[key]
 
     def pair_rep(self, X):
         """Feature-pair classes of a feature matrix, detected once per tensor (and version)."""
-        key = self._pair_key(X)
-        if key not in self._pairs:
-            if len(self._pairs) > 256:
-                self._pairs.clear()
-            self._pairs[key] = pair_classes(X)
-        return self._pairs[key]
+        rep = self._pair_lookup(X, "own")
+        if rep is _MISSING:
+            rep = pair_classes(X)
+            self._pair_store(X, "own", rep)
+        return rep
 
     def prefetch_pairs(self, Xs):
         """Detect the classes of several feature matrices in one go (all sites of a data set when the
         first Gram is asked for), so that a sweep does not stop at every new site for it."""
         todo = {}
         for X in Xs:
-            if X.ndim == 2 and 2 <= X.shape[1] <= PAIR_CLASS_MAX_P and self._pair_key(X) not in self._pairs:
-                todo.setdefault(tuple(X.shape), {})[self._pair_key(X)] = X
+            if X.ndim == 2 and 2 <= X.shape[1] <= PAIR_CLASS_MAX_P and self._pair_lookup(X, "own") is _MISSING:
+                todo.setdefault(tuple(X.shape), {})[self._pair_key(X, 'own')[1]] = X
         for group in todo.values():
-            keys = list(group)
-            for key, rep in zip(keys, pair_classes_many([group[k] for k in keys])):
-                self._pairs[key] = rep
+            tensors = list(group.values())
+            for X, rep in zip(tensors, pair_classes_many(tensors)):
+                self._pair_store(X, "own", rep)
 
     def dense_buffer(self, D, device):
         buf = self._abuf.get(D)

@@ -103,3 +103,29 @@ def test_speculative_front_is_dropped_when_nodes_change(cpu_kernels):
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert fronts > len(ref)      # every queued front was dropped and recomputed
+
+
+def test_gradient_swipe_takes_the_cifar_call(cpu_kernels):
+    conv.check_gradient_swipe_cifar_call("cpu")
+
+
+def test_pair_classes_follow_the_tensor_not_its_address(cpu_kernels):
+    """The class cache must not hand the classes of one feature tensor to another tensor, whatever
+    address, shape or version the two share; views of one tensor share an entry."""
+    import torch
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    torch.set_default_dtype(torch.float64)
+    eng = TensorTrainLayer(3, 2, 3, output_shape=1, seed=1).tensor_network._engine
+    x = torch.rand(300, 1) * 2 - 1
+    poly = torch.cat([x ** k for k in range(4)], dim=1).contiguous()       # classes by p + q
+    rep = eng.pair_rep(poly.reshape(1, 1, 300, 4)[0, 0])
+    assert rep is not None and len(set(rep)) == 7
+    assert eng.pair_rep(poly.reshape(1, 1, 300, 4)[0, 0]) is rep            # a fresh view of the same owner hits
+    # another tensor with identical metadata (what a recycled allocation looks like) must miss
+    other = torch.rand(300, 4)
+    assert other._version == poly._version and other.shape == poly.shape
+    assert eng.pair_rep(other) is None
+    poly.mul_(1.0)                                                           # new version: recomputed, same classes
+    assert eng.pair_rep(poly) == rep
+    eng.drop_pairs([poly])
+    assert all(e[0] is not poly for e in eng._pairs.values())
