@@ -113,6 +113,18 @@ int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr);
 int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b,
                 int64_t S, int C, int rl, int p, int rr, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 
+/* ttk_rhs_f64 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments, same kernels, same result bits as ttk_rhs_f64, but the slab partials live in a
+ * file-scope device array of ttk_rhs_static_max_bytes() bytes (32 MiB, held by every GPU the
+ * library runs on until the process ends) instead of a caller workspace; the call allocates and
+ * frees nothing.  Extents whose ttk_rhs_ws_bytes exceeds that size return TTK_EWORKSPACE and launch
+ * nothing.  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams) race; calls on one stream are ordered and safe. */
+int64_t ttk_rhs_static_max_bytes(void);
+int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const double* g, double* b,
+                       int64_t S, int C, int rl, int p, int rr, int accumulate, void* stream);
+
 /* Jacobian-vector product  u[s,c] = sum_{l,p,r} L[s,c,l] X[s,p] R[s,r] v[l,p,r]
  * followed by hu[s,d] = sum_c H[s,c,d] u[s,c]  (first einsum of the matrix-free
  * product, tensor/network.py:788).  tmp (S,C,rr) scratch; hu (S,C). */

@@ -35,6 +35,8 @@ SIGNATURES = {
     "ttk_gram_timing_read": (_int, [_c_dp, _int]),
     "ttk_rhs_ws_bytes": (_i64, [_i64, _int, _int, _int, _int]),
     "ttk_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_rhs_static_max_bytes": (_i64, []),
+    "ttk_rhs_static_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_jvp_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_solve_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _dbl, _c_dp, _i64, _c_dp]),
     "ttk_chol_ws_bytes": (_i64, [_int]),

@@ -10,6 +10,7 @@
 // they are generated in registers from LDS-staged tables instead of being read from HBM.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 #include <stdint.h>
 
 #include "ttk.h"
@@ -2422,6 +2423,28 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   }
 }
 
+// File-scope scratch of ttk_rhs_static_f64, the entry point for callers that cannot allocate.  Every
+// GPU the library runs on holds its own copy until the process ends.  In host code the array's name
+// is only a handle for hipGetSymbolAddress; the address kernels may use is looked up once per device,
+// with that device current, and kept.
+#define TTK_STATIC_SCRATCH_DOUBLES (4 * 1024 * 1024)   // 32 MiB
+#define TTK_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[TTK_STATIC_SCRATCH_DOUBLES];
+static double* g_scratch_ptr[TTK_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static double* static_scratch_ptr() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TTK_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess) return nullptr;
+    g_scratch_ptr[dev] = (double*)ptr;
+  }
+  return g_scratch_ptr[dev];
+}
+
 // Event pairs around the Gram kernel (diagnostic; armed by ttk_gram_timing).
 static const int kTimingPool = 512;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
@@ -2723,25 +2746,20 @@ int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {
   return ((int64_t)d.nslabs * rl * p * rr + (C > 1 ? S * rl : 0)) * (int64_t)sizeof(double);
 }
 
-int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C, int rl,
-                int p, int rr, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
-  if (!L || !X || !R || !g || !b || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
-  const RhsDims d = rhs_dims(S, C, rl, p, rr);
-  if (d.CH < 4) return TTK_EINVAL;
-  if (ws_bytes < ttk_rhs_ws_bytes(S, C, rl, p, rr)) return TTK_EWORKSPACE;
-  if (S * (int64_t)(rl > rr ? rl : rr) >= (1ll << 40)) return TTK_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+// The right-hand side with its scratch (slab partials, then GL when there are several outputs) at `ws`.
+static int rhs_run(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C,
+                   int rl, int p, int rr, int accumulate, const RhsDims& d, double* ws, hipStream_t st) {
   const int64_t D = (int64_t)rl * p * rr;
   const double* A = L;
   const double* gx = g;
   if (C > 1) {
-    double* GL = (double*)ws + (int64_t)d.nslabs * D;
+    double* GL = ws + (int64_t)d.nslabs * D;
     hipLaunchKernelGGL(rhs_gl_kernel, dim3((unsigned)((S * rl + 255) / 256)), dim3(256), 0, st, g, L, GL, S, C, rl);
     A = GL;
     gx = nullptr;
   }
   const size_t lds = (size_t)d.CH * d.W * sizeof(double);
-  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, (double*)ws);
+  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 32)
@@ -2751,6 +2769,31 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)ws,
                        d.nslabs, D, D, b, accumulate);
   return ttk_launch_status();
+}
+
+int ttk_rhs_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C, int rl,
+                int p, int rr, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L || !X || !R || !g || !b || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  const RhsDims d = rhs_dims(S, C, rl, p, rr);
+  if (d.CH < 4) return TTK_EINVAL;
+  if (ws_bytes < ttk_rhs_ws_bytes(S, C, rl, p, rr)) return TTK_EWORKSPACE;
+  if (S * (int64_t)(rl > rr ? rl : rr) >= (1ll << 40)) return TTK_EINVAL;
+  return rhs_run(L, X, R, g, b, S, C, rl, p, rr, accumulate, d, (double*)ws, (hipStream_t)stream);
+}
+
+int64_t ttk_rhs_static_max_bytes(void) { return (int64_t)TTK_STATIC_SCRATCH_DOUBLES * (int64_t)sizeof(double); }
+
+int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C,
+                       int rl, int p, int rr, int accumulate, void* stream) {
+  if (!L || !X || !R || !g || !b || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  const RhsDims d = rhs_dims(S, C, rl, p, rr);
+  if (d.CH < 4) return TTK_EINVAL;
+  if (S * (int64_t)(rl > rr ? rl : rr) >= (1ll << 40)) return TTK_EINVAL;
+  if (ttk_rhs_ws_bytes(S, C, rl, p, rr) > ttk_rhs_static_max_bytes()) return TTK_EWORKSPACE;
+  double* ws = static_scratch_ptr();
+  if (!ws) return TTK_ELAUNCH;
+  // every slab partial and every GL entry is written before it is read: nothing has to start at zero
+  return rhs_run(L, X, R, g, b, S, C, rl, p, rr, accumulate, d, ws, (hipStream_t)stream);
 }
 
 int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, void* stream) {
