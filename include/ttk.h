@@ -60,7 +60,9 @@ int ttk_kr_rows_f64(const double* L, const double* X, const double* R, double* J
  * loss (S), H all-ones*2 as the reference's (S,C,1) broadcast acts inside
  * get_A_b, tensor/network.py:188,212); kind 1: AutogradLoss(MSELoss(none))
  * (bregman.py:266-292; loss (S,C), H = 2 I); kind 2: XEAutogradBregman(w)
- * (bregman.py:189-216; y is one-hot (S,C+1); loss (S)). */
+ * (bregman.py:189-216; y (S,C+1); loss (S), gradient w(pi - y) as KLDivBregman, bregman.py:140);
+ * kind 3: the same with the gradient against the label, w(pi - onehot(argmax y)): what
+ * differentiating cross_entropy(z, argmax y) gives (bregman.py:198-204) when y is not one-hot. */
 int ttk_loss_f64(int kind, double w, const double* y_pred, const double* y, double* loss, double* g,
                  double* H, int64_t S, int C, void* stream);
 

@@ -207,17 +207,19 @@ def loss_mse(y_pred, y):
     return loss, g, H
 
 
-def loss_xe(y_pred, y, w=1.0):
-    """XEAutogradBregman(w), tensor/bregman.py:189-216, in closed form
-    (same expressions as KLDivBregman, bregman.py:121-146): logits z=[w x, 0],
-    pi = softmax(z), loss = -log pi[label], g = w (pi - y)[:C],
-    H = w^2 (diag(pi) - pi pi^T)[:C,:C].  y is one-hot over C+1 classes."""
+def loss_xe(y_pred, y, w=1.0, hard=False):
+    """Softmax cross entropy in closed form: logits z=[w x, 0], pi = softmax(z),
+    loss = -log pi[label], label = argmax y, H = w^2 (diag(pi) - pi pi^T)[:C,:C].
+    KLDivBregman (tensor/bregman.py:121-146) has g = w (pi - y)[:C]; XEAutogradBregman
+    (bregman.py:189-216) differentiates cross_entropy(z, label), i.e. g = w (pi - onehot(label))[:C]
+    (hard=True).  For one-hot y over C+1 classes the two coincide."""
     z = torch.cat((w * y_pred, torch.zeros_like(y_pred[..., :1])), dim=-1)
     log_s = torch.log_softmax(z, dim=-1)
     label = y.argmax(dim=-1)
     loss = -log_s.gather(-1, label.unsqueeze(-1)).squeeze(-1)
     s = log_s.exp()
-    g = w * (s - y)[..., :-1]
+    target = torch.nn.functional.one_hot(label, y.shape[-1]).to(s.dtype) if hard else y
+    g = w * (s - target)[..., :-1]
     H = (w ** 2) * (torch.diag_embed(s) - s.unsqueeze(-1) * s.unsqueeze(-2))[..., :-1, :-1]
     return loss, g, H
 

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void loss_kernel(int kind, double w, const dou
     loss[s] = lse - zl;
     for (int c = 0; c < C; ++c) {
       const double pc = exp(w * x[c] - lse);
-      g[s * C + c] = w * (pc - t[c]);
+      g[s * C + c] = w * (pc - (kind == 3 ? (c == label ? 1.0 : 0.0) : t[c]));
       for (int d2 = 0; d2 < C; ++d2) {
         const double pd = exp(w * x[d2] - lse);
         H[(s * C + c) * C + d2] = w * w * ((c == d2 ? pc : 0.0) - pc * pd);
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
                                                           double* __restrict__ state, int64_t D) {
   __shared__ double red[16];
   const double rho = state[0], atol = state[1];
-  if (sqrt(rho) < atol) {
+  if (sqrt(rho) < atol || rho == 0.0) {   // a zero residual (e.g. b == 0 from a zero start) is a solution: no 0/0 step
     if (threadIdx.x == 0) state[2] = 1.0;
     return;
   }
@@ -2508,7 +2508,7 @@ int ttk_predict_f64(const double* L, const double* R, double* y, int64_t S, int 
 
 int ttk_loss_f64(int kind, double w, const double* y_pred, const double* y, double* loss, double* g, double* H,
                  int64_t S, int C, void* stream) {
-  if (kind < 0 || kind > 2 || !y_pred || !y || !loss || !g || !H || S < 0 || C < 1) return TTK_EINVAL;
+  if (kind < 0 || kind > 3 || !y_pred || !y || !loss || !g || !H || S < 0 || C < 1) return TTK_EINVAL;
   if (S == 0) return TTK_OK;
   hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, w, y_pred,
                      y, loss, g, H, S, C);

@@ -75,14 +75,14 @@ def predict(L, R, out=None):
     return y
 
 
-LOSS_KINDS = {"square": 0, "mse": 1, "xe": 2}
+LOSS_KINDS = {"square": 0, "mse": 1, "xe": 2, "xe_hard": 3}
 
 
 def loss(kind, y_pred, y, w=1.0):
     """-> (loss, g (S,C), H (S,C,C)); loss is (S,) for square/xe and (S,C) for mse."""
     S, C = y_pred.shape
     k = LOSS_KINDS[kind]
-    ycols = C + 1 if k == 2 else C
+    ycols = C + 1 if k >= 2 else C
     lo = torch.empty((S, C) if k == 1 else (S,), dtype=F64, device=y_pred.device)
     g = torch.empty((S, C), dtype=F64, device=y_pred.device)
     H = torch.empty((S, C, C), dtype=F64, device=y_pred.device)
@@ -151,6 +151,7 @@ class GramWorkspace:
         mp = int(rl) * (int(rl) + 1) // 2 if sym else int(rl) * int(rl)
         self.mppad = (mp + 47) // 48 * 48    # leading extent of the compressed Gram [mppad][pairs(p,q)][nrpad]
         self.pair_rep = None                 # feature-pair classes of the last Gram computed into it
+        self.generation = 0                  # bumped by every Gram computed into this workspace
 
     @property
     def compressed(self):
@@ -175,6 +176,7 @@ def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
                                  ws.buf.data_ptr(), ws.nbytes, _stream(L))
     _lib.check(rc, "ttk_gram_f64")
     ws.pair_rep = None if pair_rep is None else [int(v) for v in pair_rep]
+    ws.generation += 1
     return ws
 
 

@@ -90,12 +90,33 @@ class Shard:
             dist.broadcast(t, src=src, group=self.group)
         return t
 
-    def gather_rows(self, local, S):
-        """Per-sample values of all ranks in global sample order: (S, ...)."""
-        full = torch.zeros((S,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    def all_true(self, flag, device):
+        """Logical AND of a host flag over the ranks (one tiny all-reduce)."""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if self.backend == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
+    def batch_mean(self, local, S, batch):
+        """Mean over the mini-batches (of `batch` consecutive global samples) of the per-batch mean
+        of per-sample values, from this rank's rows `local` (n, k): every rank sums its part of each
+        batch it touches, ONE all-reduce of the per-batch sums (number-of-batches doubles) makes
+        them global.  0-d tensor, the same on every rank."""
         lo, hi = self.bounds(S)
-        full[lo:hi] = local
-        return self.allreduce_sum_(full)
+        n, k = local.shape[0], local[0].numel() if local.shape[0] else 1
+        nb = (S + batch - 1) // batch
+        sums = torch.zeros(nb, dtype=local.dtype, device=local.device)
+        if n:
+            b0, off = lo // batch, lo % batch
+            nbl = (off + n + batch - 1) // batch
+            pad = torch.zeros((nbl * batch, k), dtype=local.dtype, device=local.device)
+            pad[off:off + n] = local.reshape(n, k)
+            sums[b0:b0 + nbl] = pad.reshape(nbl, batch * k).sum(dim=1)
+        self.allreduce_sum_(sums)
+        counts = torch.full((nb,), float(batch * k), dtype=local.dtype, device=local.device)
+        counts[-1] = float((S - (nb - 1) * batch) * k)
+        return (sums / counts).mean()
 
 
 def default_shard():

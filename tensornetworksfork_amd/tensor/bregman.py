@@ -87,10 +87,12 @@ def _autograd_grad_hess(loss, x):
 
 
 class XEAutogradBregman(BregFunction):
-    """Cross entropy on logits [w*x, 0] against one-hot y over C+1 classes
-    (tensor/bregman.py:189-216).  The reference differentiates twice with
-    autograd; the closed form pi = softmax, g = w(pi-y)[:C],
-    H = w^2 (diag(pi) - pi pi^T)[:C,:C] is what that evaluates to."""
+    """Cross entropy on logits [w*x, 0] against the label argmax(y), y over C+1 classes
+    (tensor/bregman.py:189-216).  The reference differentiates cross_entropy(z, argmax y) twice
+    with autograd; the closed form pi = softmax, g = w(pi - onehot(argmax y))[:C],
+    H = w^2 (diag(pi) - pi pi^T)[:C,:C] is what that evaluates to, soft labels included."""
+
+    _kind = "xe_hard"
 
     def __init__(self, w=1.0):
         super().__init__()
@@ -100,11 +102,14 @@ class XEAutogradBregman(BregFunction):
         if only_loss:
             z = torch.cat((self.w * x, torch.zeros_like(x[..., :1])), dim=-1)
             return F.cross_entropy(z, y.argmax(dim=-1), reduction='none')
-        return ops.loss("xe", ops.prep(x), ops.prep(y), w=self.w)
+        return ops.loss(self._kind, ops.prep(x), ops.prep(y), w=self.w)
 
 
 class KLDivBregman(XEAutogradBregman):
-    """Same closed form with the reference's constructor (tensor/bregman.py:100-146)."""
+    """The reference's closed form (tensor/bregman.py:100-146): as above but with the gradient
+    against the target probabilities themselves, g = w(pi - y)[:C]."""
+
+    _kind = "xe"
 
     def __init__(self, w=1.0, grad_clip=1e3):
         super().__init__(w)

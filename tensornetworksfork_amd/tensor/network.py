@@ -157,11 +157,16 @@ class TensorNetwork:
             H = H.expand(S, C, C)
         return ops.prep(H)
 
-    @staticmethod
-    def _hessian_symmetric(H, loss_fn=None):
+    def _hessian_symmetric(self, H, sharded=False):
+        """Whether every per-sample Hessian is symmetric (one host read when C > 1).  It selects the
+        layout of the compressed Gram and with it the size of the all-reduce message, so sharded
+        runs take the AND over the ranks."""
         if H.shape[1] == 1:
             return True
-        return bool(torch.equal(H, H.transpose(1, 2)))
+        sym = bool(torch.equal(H, H.transpose(1, 2)))
+        if sharded and self._shard is not None:
+            sym = self._shard.all_true(sym, H.device)
+        return sym
 
     def _local(self, node):
         self._require_chain()
@@ -172,8 +177,9 @@ class TensorNetwork:
 
     def _gram_matrix(self, lp, H, scale=None, ridge=0.0, out=None):
         """Dense (D,D) Gram matrix of a local problem, optionally scaled and ridged."""
-        if lp.compressed_gram(self._hessian_symmetric(H)):
-            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H))
+        sym = self._hessian_symmetric(H)
+        if lp.compressed_gram(sym):
+            ws = self._engine.gram_ws(lp, H, sym)
             return ops.gram_expand(ws, scale=scale, ridge=ridge, out=out)
         A = lp.dense_gram(H)
         if scale is not None:
@@ -297,14 +303,16 @@ class TensorNetwork:
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
         total = self._batch_mean_loss(d, loss, batch_size) if want_loss else None
         b = lp.rhs(g)
-        front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None}
-        if lp.compressed_gram(self._hessian_symmetric(H)):
+        front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None, "gen": None}
+        sym = self._hessian_symmetric(H, sharded=d.sharded)
+        if lp.compressed_gram(sym):
             # compressed symmetric Gram in the workspace, own Cholesky on it
-            ws = self._engine.gram_ws(lp, H, self._hessian_symmetric(H), shard=self._shard if d.sharded else None)
+            ws = self._engine.gram_ws(lp, H, sym, shard=self._shard if d.sharded else None)
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
                 self._shard.allreduce_gram_(ws)
                 self._shard.allreduce_sum_(b)
             front["ws"] = ws
+            front["gen"] = ws.generation   # the workspace is shared: a later Gram into it outdates this front
         else:
             # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
             A_f = lp.dense_gram(H)
@@ -334,6 +342,8 @@ class TensorNetwork:
         front = None
         if spec is not None and spec[0] == (id(d), id(node), id(y), id(loss_fn), batch_size, want_loss, self._state_sig()):
             front = spec[1]
+            if front["ws"] is not None and front["ws"].generation != front["gen"]:
+                front = None     # a callback computed another Gram matrix into the shared workspace
         if front is None:
             front = self._site_front(d, node, y, loss_fn, batch_size, want_loss)
         lp, total, b = front["lp"], front["total"], front["b"]
@@ -393,10 +403,10 @@ class TensorNetwork:
 
     def _batch_mean_loss(self, d, loss, batch_size):
         """Mean over the reference's mini-batches of per-batch mean losses (device scalar);
-        with sharded samples the per-sample losses are first put in global order."""
+        with sharded samples the ranks exchange their per-batch partial sums."""
         v = ops.prep(loss.reshape(d.S, -1))
         if d.sharded:
-            v = self._shard.gather_rows(v, d.S_total)
+            return self._shard.batch_mean(v, d.S_total, batch_size)
         return ops.batch_mean(v, batch_size)
 
     def _gradient_pass(self, d, node, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm, per_batch_update):

@@ -58,7 +58,7 @@ def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     _isolve/iterative.py), in float64 on the device.  The test runs inside the fused
     vector kernel, which freezes x once it holds; the host looks at the flag every
     `check_every` iterations only to stop queueing work."""
-    state = torch.zeros(4, dtype=b.dtype, device=b.device)
+    state = torch.zeros(5, dtype=b.dtype, device=b.device)   # [rho, atol, stopped, updates, ||b||^2]
     if x0 is None:
         xk = torch.zeros_like(b)
         r = b.clone()
@@ -67,13 +67,17 @@ def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
         r = b - matvec(xk)
     p = r.clone()
     state[0] = ops.dot(r, r)
-    state[1] = rtol * ops.dot(b, b).sqrt()
+    state[4] = ops.dot(b, b)
+    state[1] = rtol * state[4].sqrt()
     for it in range(maxiter):
         q = matvec(p)
         ops.cg_update(xk, r, p, q if q.is_contiguous() else q.contiguous(), state)
         if (it + 1) % check_every == 0 and it + 1 < maxiter and state[2].item() != 0.0:
             break
-    return xk, (0 if state[2].item() != 0.0 else maxiter)
+    st = state.tolist()     # the one host read of the solve
+    if st[4] == 0.0:        # SciPy returns b itself, i.e. zeros, for a zero right-hand side (whatever x0)
+        return torch.zeros_like(b), 0
+    return xk, (0 if st[2] != 0.0 else maxiter)
 
 
 def minres_solve(matvec, b, x0, maxiter, rtol):

@@ -25,7 +25,7 @@ def predict(L, R, out=None):
 
 def loss(kind, y_pred, y, w=1.0):
     from oracle import tt_oracle as O
-    lo, g, H = O.loss_xe(y_pred, y, w) if kind == "xe" else O.LOSSES[kind](y_pred, y)
+    lo, g, H = O.loss_xe(y_pred, y, w, hard=(kind == "xe_hard")) if kind.startswith("xe") else O.LOSSES[kind](y_pred, y)
     S, C = y_pred.shape
     return lo, g.reshape(S, C).contiguous(), H.reshape(S, C, C).contiguous()
 
@@ -51,6 +51,7 @@ class _WS:
         self.A = A
         self.dims = dims
         self.buf = A
+        self.generation = 1
 
     @property
     def compressed(self):

@@ -36,11 +36,13 @@ def main():
         sh.allreduce_sum_(A)
         sh.allreduce_sum_(b)
         ok &= bool(torch.allclose(A, A_full, rtol=1e-12, atol=1e-14)) and bool(torch.allclose(b, b_full, rtol=1e-12, atol=1e-14))
-        full_loss = sh.gather_rows(loss[lo:hi].contiguous(), S)
-        ok &= bool(torch.equal(full_loss, loss))
-        ref = sum(loss[b0:b0 + bs].mean().item() for b0 in range(0, S, bs)) / ((S + bs - 1) // bs)
-        got = sum(full_loss[b0:b0 + bs].mean().item() for b0 in range(0, S, bs)) / ((S + bs - 1) // bs)
-        ok &= abs(ref - got) < 1e-15
+        # mean of per-batch means from per-batch partial sums (loss is (S, C) here), several batch sizes
+        # incl. ones that straddle the rank boundary, a single batch and a ragged last batch
+        for bsz in (bs, 7, S, 1000, 101):
+            ref = sum(loss[b0:b0 + bsz].mean().item() for b0 in range(0, S, bsz)) / ((S + bsz - 1) // bsz)
+            got = sh.batch_mean(loss[lo:hi].contiguous(), S, bsz).item()
+            ok &= abs(ref - got) < 1e-14
+        ok &= sh.all_true(True, "cpu") and not sh.all_true(sh.rank != 0, "cpu")
         v = torch.full((3,), float(sh.rank + 1))
         sh.broadcast_(v)
         ok &= bool(torch.equal(v, torch.ones(3)))

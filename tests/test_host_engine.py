@@ -59,7 +59,7 @@ def test_conv_many_patches_host_logic(cpu_kernels, monkeypatch):
     conv.check_many_patches("cpu", monkeypatch)
 
 
-def _meddling_sweep(device, speculate):
+def _meddling_sweep(device, speculate, poke_gram=False):
     """Two sweeps during which a callback changes nodes behind the engine's back: the node visited
     next is scaled in place after every update, and one node is replaced by a new tensor."""
     import torch
@@ -91,8 +91,15 @@ def _meddling_sweep(device, speculate):
         nxt.tensor.mul_(1.01)                                   # in place: same tensor object, new version
         if len(visits) == 3:
             tn.main_nodes[0].tensor = tn.main_nodes[0].tensor * 0.99   # a new tensor object
+    def poke(NS, node):
+        i = tn.main_nodes.index(node)
+        other = tn.main_nodes[1 if i != 1 else 2]      # nodes 1..3 share one shape
+        yp = tn.forward(x, to_tensor=True)
+        _, gg, HH = SquareBregFunction().forward(yp, y)
+        tn.get_A_b(other, gg, HH)
+
     assert tn.accumulating_swipe(x, y, SquareBregFunction(), method="ridge_cholesky", eps=1.0, num_swipes=2,
-                                 batch_size=16, block_callback=meddle)
+                                 batch_size=16, block_callback=(meddle if not poke_gram else poke))
     return [n.tensor.detach().cpu().clone() for n in tn.main_nodes], len(used)
 
 
@@ -129,3 +136,15 @@ def test_pair_classes_follow_the_tensor_not_its_address(cpu_kernels):
     assert eng.pair_rep(poly) == rep
     eng.drop_pairs([poly])
     assert all(e[0] is not poly for e in eng._pairs.values())
+
+
+@pytest.mark.gpu
+def test_speculative_front_survives_a_gram_from_a_callback():
+    """A callback that computes the Gram matrix of another node of the same shape between two
+    updates overwrites the shared workspace without changing any parameter: the queued front must
+    be dropped, the sweep must give what it gives without speculation."""
+    import torch
+    ref, _ = _meddling_sweep("cuda:0", speculate=False, poke_gram=True)
+    got, _ = _meddling_sweep("cuda:0", speculate=True, poke_gram=True)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)

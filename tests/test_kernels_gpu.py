@@ -78,6 +78,45 @@ DENSE_GRAM_FLOP_BUDGET = 1.2e12   # CPU GEMM work of the dense oracle Gram that 
 
 
 @gpu
+@pytest.mark.parametrize("C", [1, 4])
+def test_xe_soft_labels(C):
+    """Targets that are not one-hot (label smoothing): XEAutogradBregman's gradient is taken against
+    the arg-max label, as differentiating cross_entropy(z, argmax y) gives (tensor/bregman.py:198-204,
+    re-evaluated here with autograd on the CPU); KLDivBregman's against the probabilities themselves
+    (bregman.py:140).  Loss and Hessian agree between the two."""
+    from tensornetworksfork_amd.tensor import bregman
+    dev = _dev()
+    S, w = 257, 0.7
+    x = _rand((S, C), 3) * 2
+    y = torch.softmax(_rand((S, C + 1), 4) * 3, dim=-1)
+    xr = x.clone().requires_grad_(True)
+    z = torch.cat((w * xr, torch.zeros_like(xr[..., :1])), dim=-1)
+    loss_r = torch.nn.functional.cross_entropy(z, y.argmax(dim=-1), reduction='none')
+    g_r = torch.autograd.grad(loss_r.sum(), xr, create_graph=True)[0]
+    H_r = torch.stack([torch.autograd.grad(g_r[:, i].sum(), xr, retain_graph=True)[0] for i in range(C)], dim=-2)
+    lo, g, H = bregman.XEAutogradBregman(w=w).forward(x.to(dev), y.to(dev))
+    assert G.rel_err(lo, loss_r.detach()) < 1e-12 and G.rel_err(g, g_r.detach()) < 1e-12 and G.rel_err(H, H_r) < 1e-12
+    lo2, g2, H2 = bregman.KLDivBregman(w=w).forward(x.to(dev), y.to(dev))
+    lo_o, g_o, H_o = O.loss_xe(x, y, w)
+    assert G.rel_err(lo2, lo_o) < 1e-12 and G.rel_err(g2, g_o) < 1e-12 and G.rel_err(H2, H_o) < 1e-12
+    lo_h, g_h, H_h = O.loss_xe(x, y, w, hard=True)
+    assert G.rel_err(g, g_h) < 1e-12 and G.rel_err(g2, g_h) > 1e-3
+
+
+@gpu
+def test_cg_zero_right_hand_side():
+    """b == 0: SciPy's cg returns zeros (with or without a start vector); no NaN from a 0/0 step."""
+    from tensornetworksfork_amd.tensor.solvers import cg_solve
+    dev = _dev()
+    M = _rand((50, 50), 1)
+    A = (M @ M.T + torch.eye(50, dtype=torch.float64)).to(dev)
+    b = torch.zeros(50, dtype=torch.float64, device=dev)
+    for x0 in (None, _rand((50,), 2).to(dev)):
+        x, info = cg_solve(lambda v: A @ v, b, x0, 20, 1e-6)
+        assert info == 0 and bool((x == 0).all())
+
+
+@gpu
 @pytest.mark.parametrize("S,C,rl,p,rr", SHAPES)
 def test_gram_rhs_matvec(S, C, rl, p, rr):
     """Right-hand side and matrix-free product of every shape against the oracle.  The Gram matrix is
