@@ -312,17 +312,27 @@ def _snap_train(tn):
     return [n.tensor.detach().clone() for n in tn.train_nodes]
 
 
-def gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind="xe"):
+def gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind="xe", dtype=torch.float64, lanczos_iters=5):
+    """dtype=torch.float32 runs the reference the way image_convolution_lanczos_CIFAR10.py does: the
+    script never sets a default dtype, so nodes, data and every intermediate are float32."""
+    torch.set_default_dtype(dtype)
+    try:
+        _gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind, dtype, lanczos_iters)
+    finally:
+        torch.set_default_dtype(torch.float64)
+
+
+def _gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind, dtype, lanczos_iters):
     layer = _conv_layer(N, r, patches, pixels, C, CB, seed)
     tn = layer.tensor_network
     g = torch.Generator().manual_seed(seed + 100)
     x = torch.rand(S, patches, pixels, generator=g) * 2 - 1
     if kind == "xe":
         lab = torch.randint(0, C + 1, (S,), generator=g)
-        y = torch.nn.functional.one_hot(lab, C + 1).to(torch.float64)
+        y = torch.nn.functional.one_hot(lab, C + 1).to(dtype)
     else:
         y = torch.randn(S, C, generator=g)
-    d = {"N": N, "patches": patches, "pixels": pixels, "r": r, "CB": CB, "C": C, "S": S, "seed": seed, "x": x, "y": y,
+    d = {"dtype": np.array(str(dtype).replace("torch.", "")), "N": N, "patches": patches, "pixels": pixels, "r": r, "CB": CB, "C": C, "S": S, "seed": seed, "x": x, "y": y,
          "loss_kind": np.array(kind), "train_names": np.array([n.name for n in tn.train_nodes])}
     for i, t in enumerate(_snap_train(tn)):
         d[f"node{i}"] = t
@@ -353,9 +363,10 @@ def gen_conv(tag, N, patches, pixels, r, CB, C, S, seed, kind="xe"):
             for u, n in enumerate(tn2.train_nodes):
                 d[f"lanczos_x0_{u}"] = torch.randn_like(n.tensor)
             torch.manual_seed(seed + 5)
-            ok = tn2.lanczos_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=1, max_iter=5, tol=1e-6,
+            ok = tn2.lanczos_swipe(x, y, make_loss(kind), batch_size=32, num_swipes=1, max_iter=lanczos_iters, tol=1e-6,
                                    loss_callback=lambda l: losses.append(l),
                                    block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+            d["lanczos_max_iter"] = lanczos_iters
         d[f"{which}_ok"] = int(ok)
         d[f"{which}_losses"] = np.array(losses)
         d[f"{which}_num_updates"] = len(snaps)
@@ -459,5 +470,20 @@ def gen_extra():
               num_swipes=3, batch_size=512)
 
 
+def gen_many_patches():
+    """Conv columns with at least 16 patches (the sites of the MNIST / CIFAR configurations have 50 /
+    65): the build contracts the features of such a site first, a different code route from the
+    10-patch fixtures above.  One of them in float32, the arithmetic type of the CIFAR script."""
+    # three Lanczos iterations: fewer than the 5 unknowns of a filter node, whose Krylov space five
+    # iterations exhaust (the tridiagonal system then sits at the edge of breakdown and its solution is
+    # rounding noise, in the reference as anywhere)
+    gen_conv("p17_cbm1", 3, 17, 5, 4, -1, 3, 64, 51, lanczos_iters=3)
+    gen_conv("p17_cb2", 3, 17, 5, 4, 2, 3, 64, 52, lanczos_iters=3)
+    gen_conv("p17_cbm1_f32", 3, 17, 5, 4, -1, 3, 64, 53, dtype=torch.float32, lanczos_iters=3)
+    gen_conv("p10_cb2_f32", 3, 10, 5, 4, 2, 3, 64, 54, dtype=torch.float32, lanczos_iters=3)
+
+
 if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_EXTRA", "1") == "1":
     gen_extra()
+if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_MANY_PATCHES", "1") == "1":
+    gen_many_patches()
