@@ -187,8 +187,18 @@ int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, i
  * ttk_lanczos_update_f64: iteration j >= 1 of the Lanczos recurrence of lanczos_solver
  * (tensor/network.py:796-824) with w = A v_cur on entry:  w -= betas[j-1] v_prev (skipped when
  * v_prev is NULL: the reference's zero vector of the first iteration), alphas[j-1] = <w,v_cur>,
- * w -= alphas[j-1] v_cur, betas[j] = ||w||, v_next = w / betas[j]. */
+ * w -= alphas[j-1] v_cur, betas[j] = ||w||, v_next = w / betas[j].
+ *
+ * ttk_minres_update_f64: the vector half of one iteration of scipy.sparse.linalg.minres (no shift, no
+ * preconditioner; the other solver scipy_swipe is used with, CIFAR_minres.py:112 through
+ * tensor/network.py:923-924), recurrence and stopping rules of SciPy's _isolve/minres.py.  On entry
+ * y = A v.  state (18 doubles on the device) = [istop, itn, oldb, beta, dbar, epsln, phibar, rhs1, rhs2,
+ * tnorm2, gmax, gmin, cs, sn, beta1, rtol, maxiter, machine eps]; istop != 0 (SciPy's codes; 6 =
+ * iteration limit) freezes everything, so calls queued behind the last iteration are no-ops.  On exit
+ * v is the next Lanczos vector (the next product's operand), x the current solution. */
 int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* stream);
+int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
+                          int64_t D, void* stream);
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, void* stream);
 

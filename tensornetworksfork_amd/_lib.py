@@ -48,6 +48,7 @@ SIGNATURES = {
     "ttk_axpy_f64": (_int, [_c_dp, _dbl, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_cg_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
+    "ttk_minres_update_f64": (_int, [_c_dp] * 8 + [_i64, _c_dp]),
     "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _c_dp]),
 }
 

@@ -1577,6 +1577,102 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict
   }
 }
 
+// The vector half of one MINRES iteration (Paige & Saunders, as scipy.sparse.linalg.minres runs it
+// without shift or preconditioner) in one workgroup; every scalar of the recurrence lives in `st`
+// on the device, so the host never reads anything inside the loop.  On entry y = A v.
+// st: 0 istop (0 = running; SciPy's codes, 6 = iteration limit, -1 = beta2 = 0), 1 itn, 2 oldb, 3 beta,
+//     4 dbar, 5 epsln, 6 phibar, 7 rhs1, 8 rhs2, 9 tnorm2, 10 gmax, 11 gmin, 12 cs, 13 sn, 14 beta1,
+//     15 rtol, 16 maxiter, 17 machine epsilon.
+// Vectors: y (A v in, r2 of the new iteration out), r1, r2, v (next Lanczos vector out), w, w2, x.
+// Once istop != 0 the kernel returns at once: calls queued behind the last iteration change nothing.
+__global__ __launch_bounds__(1024) void minres_update_kernel(double* __restrict__ y, double* __restrict__ r1,
+                                                              double* __restrict__ r2, double* __restrict__ v,
+                                                              double* __restrict__ w, double* __restrict__ w2,
+                                                              double* __restrict__ x, double* __restrict__ st,
+                                                              int64_t D) {
+  __shared__ double red[16];
+  if (st[0] != 0.0) return;
+  const double itn = st[1] + 1.0;
+  double oldb = st[2], beta = st[3], dbar = st[4], epsln = st[5], phibar = st[6], rhs1 = st[7], rhs2 = st[8];
+  double tnorm2 = st[9], gmax = st[10], gmin = st[11], cs = st[12], sn = st[13];
+  const double beta1 = st[14], rtol = st[15], maxiter = st[16], eps = st[17];
+  // y <- A v - (beta / oldb) r1;  alfa = <v, y>
+  const double c1 = itn >= 2.0 ? beta / oldb : 0.0;
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    const double yk = itn >= 2.0 ? y[k] - c1 * r1[k] : y[k];
+    y[k] = yk;
+    acc += v[k] * yk;
+  }
+  const double alfa = block_sum_1024(acc, red);
+  // y <- y - (alfa / beta) r2;  r1 <- r2;  r2 <- y;  beta' = ||y||
+  const double c2 = alfa / beta;
+  acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    const double r2k = r2[k];
+    const double yk = y[k] - c2 * r2k;
+    r1[k] = r2k;
+    r2[k] = yk;
+    acc += yk * yk;
+  }
+  oldb = beta;
+  beta = sqrt(block_sum_1024(acc, red));
+  tnorm2 += alfa * alfa + oldb * oldb + beta * beta;
+  double istop = 0.0;
+  if (itn == 1.0 && beta / beta1 <= 10.0 * eps) istop = -1.0;
+  const double oldeps = epsln;
+  const double delta = cs * dbar + sn * alfa;
+  const double gbar = sn * dbar - cs * alfa;
+  epsln = sn * beta;
+  dbar = -cs * beta;
+  const double root = hypot(gbar, dbar);
+  const double gamma = fmax(hypot(gbar, beta), eps);
+  cs = gbar / gamma;
+  sn = beta / gamma;
+  const double phi = cs * phibar;
+  phibar = sn * phibar;
+  const double denom = 1.0 / gamma;
+  // w1 <- w2; w2 <- w; w <- (v - oldeps w1 - delta w2) / gamma;  x += phi w;  v <- y / beta' (the next Lanczos vector)
+  const double rb = 1.0 / beta;
+  acc = 0.0;
+  for (int64_t k = threadIdx.x; k < D; k += 1024) {
+    const double w1k = w2[k], w2k = w[k];
+    const double wk = (v[k] - oldeps * w1k - delta * w2k) * denom;
+    w2[k] = w2k;
+    w[k] = wk;
+    const double xk = x[k] + phi * wk;
+    x[k] = xk;
+    acc += xk * xk;
+    v[k] = rb * r2[k];
+  }
+  const double ynorm = sqrt(block_sum_1024(acc, red));
+  gmax = fmax(gmax, gamma);
+  gmin = fmin(gmin, gamma);
+  const double z = rhs1 / gamma;
+  rhs1 = rhs2 - delta * z;
+  rhs2 = -epsln * z;
+  const double Anorm = sqrt(tnorm2);
+  const double epsx = Anorm * ynorm * eps;
+  const double rnorm = phibar;
+  const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+  const double test2 = Anorm == 0.0 ? INFINITY : root / Anorm;
+  const double Acond = gmax / gmin;
+  if (istop == 0.0) {
+    const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+    if (t2 <= 1.0) istop = 2.0;
+    if (t1 <= 1.0) istop = 1.0;
+    if (itn >= maxiter) istop = 6.0;
+    if (Acond >= 0.1 / eps) istop = 4.0;
+    if (epsx >= beta1) istop = 3.0;
+    if (test2 <= rtol) istop = 2.0;
+    if (test1 <= rtol) istop = 1.0;
+  }
+  if (threadIdx.x == 0) {
+    st[0] = istop; st[1] = itn; st[2] = oldb; st[3] = beta; st[4] = dbar; st[5] = epsln; st[6] = phibar;
+    st[7] = rhs1; st[8] = rhs2; st[9] = tnorm2; st[10] = gmax; st[11] = gmin; st[12] = cs; st[13] = sn;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky with the right-hand side carried as an extra block row.
 //
@@ -2869,6 +2965,13 @@ int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* 
     hipLaunchKernelGGL(cg_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
   else
     hipLaunchKernelGGL(cg_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
+  return ttk_launch_status();
+}
+
+int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
+                          int64_t D, void* stream) {
+  if (!y || !r1 || !r2 || !v || !w || !w2 || !x || !state || D < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(minres_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, y, r1, r2, v, w, w2, x, state, D);
   return ttk_launch_status();
 }
 

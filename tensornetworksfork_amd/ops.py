@@ -342,6 +342,13 @@ def cg_update(x, r, p, q, state):
     _lib.check(rc, "ttk_cg_update_f64")
 
 
+def minres_update(y, r1, r2, v, w, w2, x, state):
+    """One MINRES vector update in place (y = A v on entry); see ttk_minres_update_f64."""
+    rc = _lib.lib().ttk_minres_update_f64(_chk(y, "y"), _chk(r1, "r1"), _chk(r2, "r2"), _chk(v, "v"), _chk(w, "w"),
+                                          _chk(w2, "w2"), _chk(x, "x"), _chk(state, "state"), x.numel(), _stream(x))
+    _lib.check(rc, "ttk_minres_update_f64")
+
+
 def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
     """Iteration j >= 1 of the Lanczos recurrence on w = A v_cur (in place); returns v_next.
     alphas[j-1] and betas[j] are written on the device; v_prev may be None (first iteration)."""

@@ -80,112 +80,42 @@ def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     return xk, (0 if st[2] != 0.0 else maxiter)
 
 
-def minres_solve(matvec, b, x0, maxiter, rtol):
+def minres_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     """MINRES (Paige & Saunders) following scipy.sparse.linalg.minres (SciPy 1.15
-    _isolve/minres.py) without shift or preconditioner; scalars live on the host
-    as in SciPy, vectors stay on the device."""
-    import math
-    n = b.numel()
-    eps = torch.finfo(b.dtype).eps
-    xk = torch.zeros_like(b) if x0 is None else x0.clone()
-    r1 = b.clone() if x0 is None else b - matvec(xk)
-    y = r1
-    beta1 = ops.dot(r1, y).item()
-    if beta1 < 0:
-        raise ValueError('indefinite preconditioner')
-    if beta1 == 0:
-        return xk, 0
-    bnorm = ops.dot(b, b).sqrt().item()
-    if bnorm == 0:
-        return b.clone(), 0
-    beta1 = math.sqrt(beta1)
-    oldb, beta, dbar, epsln, qrnorm, phibar, rhs1, rhs2 = 0.0, beta1, 0.0, 0.0, beta1, beta1, beta1, 0.0
-    tnorm2, gmax, gmin = 0.0, 0.0, float(torch.finfo(b.dtype).max)
-    cs, sn = -1.0, 0.0
+    _isolve/minres.py) without shift or preconditioner, in float64 on the device.  Every scalar of
+    the recurrence stays in a device state vector that one fused kernel per iteration updates next
+    to the vectors; the stopping tests run inside it and freeze x once one holds, so the host reads
+    the state once before the loop (SciPy's early exits on beta1) and then only every
+    `check_every` iterations, to stop queueing work."""
+    shape = b.shape
+    b = b.reshape(-1)
+    eps = float(torch.finfo(b.dtype).eps)
+    xk = torch.zeros_like(b) if x0 is None else x0.reshape(-1).clone()
+    r1 = b.clone() if x0 is None else b - matvec(xk.reshape(shape)).reshape(-1)
+    head = torch.stack((ops.dot(r1, r1), ops.dot(b, b))).tolist()     # one host read
+    beta1sq, bnorm2 = head
+    if beta1sq == 0:
+        return xk.reshape(shape), 0
+    if bnorm2 == 0:
+        return b.clone().reshape(shape), 0
+    beta1 = beta1sq ** 0.5
+    st = torch.zeros(18, dtype=b.dtype)
+    # [istop, itn, oldb, beta, dbar, epsln, phibar, rhs1, rhs2, tnorm2, gmax, gmin, cs, sn, beta1, rtol, maxiter, eps]
+    st[3], st[6], st[7], st[14] = beta1, beta1, beta1, beta1
+    st[11] = float(torch.finfo(b.dtype).max)
+    st[12], st[15], st[16], st[17] = -1.0, rtol, float(maxiter), eps
+    st = st.to(b.device)
+    r2 = r1.clone()
+    v = r1 / beta1
     w = torch.zeros_like(b)
     w2 = torch.zeros_like(b)
-    r2 = r1
-    istop, itn = 0, 0
-    Anorm = Acond = rnorm = ynorm = 0.0
-    while itn < maxiter:
-        itn += 1
-        s = 1.0 / beta
-        v = s * y
-        y = matvec(v)
-        if itn >= 2:
-            y = y - (beta / oldb) * r1
-        alfa = ops.dot(v, y).item()
-        y = y - (alfa / beta) * r2
-        r1 = r2
-        r2 = y
-        oldb = beta
-        beta = ops.dot(r2, y).item()
-        if beta < 0:
-            raise ValueError('non-symmetric matrix')
-        beta = math.sqrt(beta)
-        tnorm2 += alfa ** 2 + oldb ** 2 + beta ** 2
-        if itn == 1:
-            if beta / beta1 <= 10 * eps:
-                istop = -1
-        oldeps = epsln
-        delta = cs * dbar + sn * alfa
-        gbar = sn * dbar - cs * alfa
-        epsln = sn * beta
-        dbar = -cs * beta
-        root = math.hypot(gbar, dbar)
-        Arnorm = phibar * root
-        gamma = max(math.hypot(gbar, beta), eps)
-        cs = gbar / gamma
-        sn = beta / gamma
-        phi = cs * phibar
-        phibar = sn * phibar
-        denom = 1.0 / gamma
-        w1 = w2
-        w2 = w
-        w = (v - oldeps * w1 - delta * w2) * denom
-        xk = xk + phi * w
-        gmax = max(gmax, gamma)
-        gmin = min(gmin, gamma)
-        z = rhs1 / gamma
-        rhs1 = rhs2 - delta * z
-        rhs2 = -epsln * z
-        Anorm = math.sqrt(tnorm2)
-        ynorm = ops.dot(xk, xk).sqrt().item()
-        epsa = Anorm * eps
-        epsx = Anorm * ynorm * eps
-        epsr = Anorm * ynorm * rtol
-        diag = gbar if gbar != 0 else epsa
-        qrnorm = phibar
-        rnorm = qrnorm
-        if ynorm == 0 or Anorm == 0:
-            test1 = float('inf')
-        else:
-            test1 = rnorm / (Anorm * ynorm)
-        if Anorm == 0:
-            test2 = float('inf')
-        else:
-            test2 = root / Anorm
-        Acond = gmax / gmin
-        if istop == 0:
-            t1 = 1 + test1
-            t2 = 1 + test2
-            if t2 <= 1:
-                istop = 2
-            if t1 <= 1:
-                istop = 1
-            if itn >= maxiter:
-                istop = 6
-            if Acond >= 0.1 / eps:
-                istop = 4
-            if epsx >= beta1:
-                istop = 3
-            if test2 <= rtol:
-                istop = 2
-            if test1 <= rtol:
-                istop = 1
-        if istop != 0:
+    for it in range(maxiter):
+        y = matvec(v.reshape(shape)).reshape(-1)
+        ops.minres_update(y if y.is_contiguous() else y.contiguous(), r1, r2, v, w, w2, xk, st)
+        if (it + 1) % check_every == 0 and it + 1 < maxiter and st[0].item() != 0.0:
             break
-    return xk, (maxiter if istop == 6 else 0)
+    istop = st[0].item()
+    return xk.reshape(shape), (maxiter if istop == 6.0 else 0)
 
 
 def _scipy_kind(solver):

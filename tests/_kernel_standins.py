@@ -147,6 +147,71 @@ def cg_update(x, r, p, q, state):
     state[3] += 1.0
 
 
+def minres_update(y, r1, r2, v, w, w2, x, st):
+    """scipy.sparse.linalg.minres (SciPy 1.15 _isolve/minres.py), one pass of its loop body on
+    the state vector layout of ttk_minres_update_f64."""
+    import math
+    if float(st[0]) != 0.0:
+        return
+    (_, itn, oldb, beta, dbar, epsln, phibar, rhs1, rhs2, tnorm2, gmax, gmin, cs, sn, beta1, rtol, maxiter,
+     eps) = [float(t) for t in st]
+    itn += 1
+    if itn >= 2:
+        y.sub_((beta / oldb) * r1)
+    alfa = float((v * y).sum())
+    y.sub_((alfa / beta) * r2)
+    r1.copy_(r2)
+    r2.copy_(y)
+    oldb = beta
+    beta = math.sqrt(float((y * y).sum()))
+    tnorm2 += alfa ** 2 + oldb ** 2 + beta ** 2
+    istop = 0
+    if itn == 1 and beta / beta1 <= 10 * eps:
+        istop = -1
+    oldeps = epsln
+    delta = cs * dbar + sn * alfa
+    gbar = sn * dbar - cs * alfa
+    epsln = sn * beta
+    dbar = -cs * beta
+    root = math.hypot(gbar, dbar)
+    gamma = max(math.hypot(gbar, beta), eps)
+    cs = gbar / gamma
+    sn = beta / gamma
+    phi = cs * phibar
+    phibar = sn * phibar
+    w1 = w2.clone()
+    w2.copy_(w)
+    w.copy_((v - oldeps * w1 - delta * w2) / gamma)
+    x.add_(phi * w)
+    v.copy_(r2 / beta)
+    gmax, gmin = max(gmax, gamma), min(gmin, gamma)
+    z = rhs1 / gamma
+    rhs1 = rhs2 - delta * z
+    rhs2 = -epsln * z
+    Anorm = math.sqrt(tnorm2)
+    ynorm = math.sqrt(float((x * x).sum()))
+    epsx = Anorm * ynorm * eps
+    test1 = float('inf') if ynorm == 0 or Anorm == 0 else phibar / (Anorm * ynorm)
+    test2 = float('inf') if Anorm == 0 else root / Anorm
+    if istop == 0:
+        if 1 + test2 <= 1:
+            istop = 2
+        if 1 + test1 <= 1:
+            istop = 1
+        if itn >= maxiter:
+            istop = 6
+        if gmax / gmin >= 0.1 / eps:
+            istop = 4
+        if epsx >= beta1:
+            istop = 3
+        if test2 <= rtol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+    for k, val in enumerate((istop, itn, oldb, beta, dbar, epsln, phibar, rhs1, rhs2, tnorm2, gmax, gmin, cs, sn)):
+        st[k] = val
+
+
 def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
     if v_prev is not None:
         w.sub_(betas[j - 1] * v_prev)
@@ -159,7 +224,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update gl rhs_supported").split()
+         "matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
 
 
 def install(monkeypatch):
