@@ -82,8 +82,12 @@ def run_updates(tn, F, y, F_val, y_val, n_updates, eps0=1.0):
 
 
 def cg_variant(device, F, y, steps):
-    """Matrix-free CG (scipy.sparse.linalg.cg semantics, max_iter=100, rtol=1e-6) on middle sites."""
+    """Matrix-free CG (scipy.sparse.linalg.cg semantics, max_iter=100, rtol=1e-6) on middle sites: the
+    solver BASELINE's configuration list names for this model.  One iteration = the fused product
+    kernel (J^T H J p in one pass over the samples, direction update in its prologue) + the slab
+    reduction with the x / r updates; its roofline entry is the product kernel's."""
     import scipy.sparse.linalg as spla
+    from tensornetworksfork_amd import ops
     from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
     layer = make_model(device)
     tn = layer.tensor_network
@@ -92,22 +96,31 @@ def cg_variant(device, F, y, steps):
         tn.train_nodes = tn.main_nodes[2:3]
         tn.scipy_swipe(F, y, SquareBregFunction(), spla.cg, batch_size=512, max_iter=100, tol=1e-6)   # warm-up
         tn.train_nodes = tn.main_nodes[3:3 + steps]
+        ops.gram_timing(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tn.scipy_swipe(F, y, SquareBregFunction(), spla.cg, batch_size=512, max_iter=100, tol=1e-6)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        mv_ms = ops.gram_timing_read()
+        ops.gram_timing(0)
     finally:
         tn.train_nodes = all_nodes
     S, D = F[0].shape[0], BOND * (DEGREE + 1) * BOND
     per = dt / steps
-    it_bytes = S * (BOND + DEGREE + 1 + BOND + 2) * 8.0
+    it_bytes = S * (BOND + DEGREE + 1 + BOND + 1) * 8.0
+    it_flops = 4.0 * S * D
+    avg_ms = float(np.mean(mv_ms)) if mv_ms else float("nan")
+    tfl = it_flops / (avg_ms * 1e-3) * 1e-12
     return {"value": 1.0 / per, "unit": "core-updates/s", "ms_per_step": per * 1e3, "steps": steps, "max_iter": 100,
-            "rtol": 1e-6, "samples_per_sec": S / per,
-            "matvec_algorithmic": {"flops_per_iter": 4.0 * S * D, "bytes_per_iter": it_bytes,
-                                   "iters_per_update_upper_bound": 101,
-                                   "hbm_gbs_lower_bound": 101 * it_bytes / per * 1e-9,
-                                   "hbm_frac_lower_bound": 101 * it_bytes / per * 1e-9 / HBM_PEAK_GBS}}
+            "rtol": 1e-6, "samples_per_sec": S / per, "iterations_timed": len(mv_ms),
+            "us_per_iteration": per * 1e6 / 100.0,
+            "roofline": {"kernel": "matvec_fused_kernel<8,3,1>", "bound": "mfma", "achieved": tfl,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP64_MFMA_PEAK_TFLOPS,
+                         "avg_launch_us": avg_ms * 1e3, "flops_per_launch": it_flops,
+                         "algorithmic_bytes_per_launch": it_bytes,
+                         "hbm_gbs": it_bytes / (avg_ms * 1e-3) * 1e-9,
+                         "hbm_frac": it_bytes / (avg_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, "traffic": None}}
 
 
 def parity_and_cpu_baseline(device, F, y, sites=(6, 7, 8), eps=1.0):

@@ -101,7 +101,8 @@ int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, con
 /* Timing of the Gram kernel with HIP events recorded on the launch stream (no
  * counterpart in the reference; used by bench.py for the roofline figure).
  * ttk_gram_timing(1) creates a pool of event pairs and arms recording around every
- * subsequent Gram kernel launch; ttk_gram_timing(0) disarms.  ttk_gram_timing_read
+ * subsequent Gram kernel launch (ttk_gram_timing(2): around every launch of the fused
+ * matrix-free product kernel instead); ttk_gram_timing(0) disarms.  ttk_gram_timing_read
  * waits for the recorded pairs, writes up to `max` durations (milliseconds, launch
  * order) to ms_out (HOST pointer), clears the list and returns how many it wrote. */
 int ttk_gram_timing(int enable);
@@ -132,6 +133,26 @@ int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const 
  * product, tensor/network.py:788).  tmp (S,C,rr) scratch; hu (S,C). */
 int ttk_jvp_f64(const double* L, const double* X, const double* R, const double* H, const double* v,
                 double* tmp, double* hu, int64_t S, int C, int rl, int p, int rr, void* stream);
+
+/* Matrix-free product (J^T H J) v in one pass over the samples, for one output (C = 1, H one number
+ * per sample or NULL = 1) and square bonds rl = rr in {16, 32} with p <= 8 features: the two einsums
+ * of the reference's matvec closure (tensor/network.py:788-789) fused, the samples read once.
+ * ttk_matvec_fused_ws_bytes returns TTK_EINVAL for extents this kernel does not take (callers then
+ * use ttk_jvp_f64 + ttk_rhs_f64).
+ *
+ * ttk_cg_fused_iter_f64: iteration `it` (0, 1, 2, ...) of scipy.sparse.linalg.cg on that operator
+ * (scipy_swipe with solver = cg, tensor/network.py:923-924) as two launches and no host read:
+ *   p = r + (rho/rho_old) p_old  (p = r for it = 0), q = A p, alpha = rho / <p,q>, x += alpha p,
+ *   r -= alpha q, after SciPy's stopping test sqrt(rho) < atol on the current residual.
+ * pbuf holds two vectors (2 D doubles: p of even / odd iterations); state (5 doubles on the device) =
+ * [rho of even its, rho of odd its, atol, stopped, iterations done]; before it = 0 the caller sets
+ * state = [0, <r,r>, atol, 0, 0].  Once the test holds `stopped` is set and every later call is a no-op. */
+int64_t ttk_matvec_fused_ws_bytes(int64_t S, int C, int rl, int p, int rr);
+int ttk_matvec_fused_f64(const double* L, const double* X, const double* R, const double* H, const double* v,
+                         double* out, int64_t S, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream);
+int ttk_cg_fused_iter_f64(const double* L, const double* X, const double* R, const double* H, double* x, double* r,
+                          double* pbuf, double* state, int it, int64_t S, int rl, int p, int rr, void* ws,
+                          int64_t ws_bytes, void* stream);
 
 /* Right-hand side of the scaled, ridge-shifted system, negated:
  *   out[i] = -( b[i] / scale[0] + ridge * w[i] )            (network.py:302,309,313,315)

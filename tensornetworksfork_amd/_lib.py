@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttk.so")
+LIB_PATH = os.environ.get("TTK_LIB_PATH") or os.path.join(_HERE, "libttk.so")   # (override: diagnostic builds)
 SRC_PATH = os.path.join(_HERE, "csrc", "ttk.hip")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -37,6 +37,9 @@ SIGNATURES = {
     "ttk_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_rhs_static_max_bytes": (_i64, []),
     "ttk_rhs_static_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
+    "ttk_matvec_fused_ws_bytes": (_i64, [_i64, _int, _int, _int, _int]),
+    "ttk_matvec_fused_f64": (_int, [_c_dp] * 6 + [_i64, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_cg_fused_iter_f64": (_int, [_c_dp] * 8 + [_int, _i64, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_jvp_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_solve_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _dbl, _c_dp, _i64, _c_dp]),
     "ttk_chol_ws_bytes": (_i64, [_int]),

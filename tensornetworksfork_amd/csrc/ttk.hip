@@ -1370,6 +1370,375 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
   }
 }
 
+// Sum over the 256 threads of a workgroup, the same value on every thread; fixed order.
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();   // red may still be read from the previous sum
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused matrix-free product for one output and square bonds e = n in {16, 32}, p <= 8 (every
+// middle site of a tensor train with one output):
+//   q = J^T (h o (J v)),   J[s,(l,pp,r)] = L[s,l] X[s,pp] R[s,r]
+// in ONE pass over the samples.  One workgroup of eight waves per compute unit owns a slab of samples
+// and keeps the vector v (as the (e p) x n matrix of the step  L (x) X -> R) in LDS.  The waves split
+// into two groups that work on consecutive chunks of 64 samples at the same time, so that each SIMD
+// always holds one wave of either kind and the matrix pipe stays fed while the other wave loads,
+// shuffles or stores:
+//   waves 0-3 (chunk c)    u_s = h_s <(L_s (x) X_s) v, R_s> for 16 samples each: the operand
+//                          L[s,l] X[s,pp] is formed in registers from rows fetched straight from
+//                          memory one chunk ahead (lane = sample row), the result is dotted with R_s;
+//                          the wave then leaves its rows [L | X | R | u] in the LDS image of chunk c;
+//   waves 4-7 (chunk c-1)  acc[l,(pp,r)] += sum_s (u_s L[s,l]) X[s,pp] R[s,r] from the image of chunk
+//                          c-1, a wave owns 2 (1 for e = 16) x TW output tiles across all chunks.
+// One barrier per chunk hands an image over.  Each workgroup writes its own partial q (summed in fixed
+// order by a second kernel) and its part of <v, q> = sum_s u_s (J v)_s, which conjugate gradients need.
+// MODE 1 is one conjugate-gradient iteration's first half: the vector is p = r + beta p_old, formed
+// while it is staged (beta from the partial sums of <r, r> the previous iteration left; workgroup 0
+// stores p and the new rho), and the stopping test of scipy.sparse.linalg.cg runs first.
+// cgst = [rho slot 0, rho slot 1, atol, stopped, iterations done].
+// ---------------------------------------------------------------------------------------
+#define MVF_CH 64
+__device__ __forceinline__ double block_sum_512(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+template <int E4, int TW, int MODE>
+__global__ __launch_bounds__(512, 2) void matvec_fused_kernel(
+    const double* __restrict__ Lg, const double* __restrict__ Xg, const double* __restrict__ Rg,
+    const double* __restrict__ Hg, const double* __restrict__ vsrc, const double* __restrict__ pold,
+    double* __restrict__ pnew, double* __restrict__ cgst, const double* __restrict__ rho_part, int nrp, int it,
+    int64_t S, int p, int64_t slab_len, int W, double* __restrict__ partial, double* __restrict__ pq_part) {
+  extern __shared__ double smem[];
+  __shared__ double red[8];
+  constexpr int e = 4 * E4, n = e, MT = e / 16, NT = e / 16;
+  const int K = e * p, N = p * n, D = K * n;
+  double* Bs = smem;                   // [K][n]
+  double* img0 = Bs + D;               // two images [MVF_CH][W]: L | X | R | u | 0
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  double beta = 0.0;
+  if (MODE == 1) {
+    if (cgst[3] != 0.0) return;
+    double rho_new;
+    if (it == 0) {
+      rho_new = cgst[1];
+    } else {
+      double a = 0.0;
+      for (int k = tid; k < nrp; k += 512) a += rho_part[k];
+      rho_new = block_sum_512(a, red);
+    }
+    if (sqrt(rho_new) < cgst[2] || rho_new == 0.0) {
+      if (blockIdx.x == 0 && tid == 0) cgst[3] = 1.0;
+      return;
+    }
+    if (it > 0) beta = rho_new / cgst[(it + 1) & 1];
+    if (blockIdx.x == 0 && tid == 0) cgst[it & 1] = rho_new;
+  }
+  const int64_t s_begin = (int64_t)blockIdx.x * slab_len;
+  int64_t s_end = s_begin + slab_len;
+  if (s_end > S) s_end = S;
+#if defined(MVF_DIAG) && (MVF_DIAG & 8)
+  s_end = s_begin;
+#endif
+  const int nchunks = s_end > s_begin ? (int)((s_end - s_begin + MVF_CH - 1) / MVF_CH) : 0;
+  // ---- producer registers: rows of the next chunk, fetched before the vector is staged
+  double er[E4], xr[8], rv[4][NT], hv[4];
+  auto fetch = [&](int c) {   // tile `wave` of chunk c; rows past the slab end are clamped here and zeroed at use
+    const int64_t row0 = s_begin + (int64_t)c * MVF_CH + wave * 16;
+    const int64_t last = s_end - 1;
+    const int64_t ri = min(row0 + i, last);
+    const double* es = Lg + ri * e + kq;
+    const double* xs = Xg + ri * p;
+#pragma unroll
+    for (int u = 0; u < E4; ++u) er[u] = es[4 * u];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xr[q] = xs[min(q, p - 1)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t rt_ = min(row0 + kq + 4 * t, last);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) rv[t][j] = Rg[rt_ * n + j * 16 + i];
+      hv[t] = Hg ? Hg[rt_] : 1.0;
+    }
+  };
+  if (wave < 4 && nchunks > 0) fetch(0);
+  for (int k0 = tid; k0 < D; k0 += 512 * 12) {   // twelve per thread in flight: the headline core in one batch
+    double a[12], b[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int k = min(k0 + 512 * u, D - 1);
+      a[u] = vsrc[k];
+      b[u] = (MODE == 1 && it > 0) ? pold[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int k = k0 + 512 * u;
+      if (k < D) {
+        const double val = MODE == 1 ? a[u] + beta * b[u] : a[u];
+        Bs[k] = val;
+        if (MODE == 1 && blockIdx.x == 0) pnew[k] = val;
+      }
+    }
+  }
+  for (int k = tid; k < 2 * MVF_CH; k += 512) img0[k * W + W - 1] = 0.0;
+  // ---- consumer set-up: rows l = u 16 + i, columns (pp, r) = ((wave - 4) TW + v) 16 + i
+  int oX[TW], oR[TW];
+#pragma unroll
+  for (int v = 0; v < TW; ++v) {
+    const int col = (((wave - 4) & 3) * TW + v) * 16 + i;
+    if (col < N) {
+      const int pn = col / n;
+      oX[v] = e + pn;
+      oR[v] = e + p + (col - pn * n);
+    } else {
+      oX[v] = oR[v] = W - 1;
+    }
+  }
+  d4 acc[MT][TW];
+#pragma unroll
+  for (int u = 0; u < MT; ++u)
+#pragma unroll
+    for (int v = 0; v < TW; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+  double pq_acc = 0.0;
+  const int ucol = 2 * e + p;
+  __syncthreads();   // the vector is staged
+  for (int c = 0; c <= nchunks; ++c) {
+    if (wave < 4) {
+      if (c < nchunks) {
+        const int nvalid = (int)min((int64_t)MVF_CH, s_end - s_begin - (int64_t)c * MVF_CH);
+        double* img = img0 + (c & 1) * MVF_CH * W;
+        if (wave * 16 < nvalid) {   // wave-uniform
+          const bool rowok = wave * 16 + i < nvalid;
+          double ec[E4], xc[8], rc[4][NT], hc[4];
+#pragma unroll
+          for (int u = 0; u < E4; ++u) ec[u] = rowok ? er[u] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xc[q] = xr[q];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool ok = wave * 16 + kq + 4 * t < nvalid;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) rc[t][j] = ok ? rv[t][j] : 0.0;
+            hc[t] = hv[t];
+          }
+          if (c + 1 < nchunks) fetch(c + 1);
+          // two accumulator sets (even / odd l-groups): four independent chains keep the matrix pipe issuing
+          d4 a1[NT], a2[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) a1[j] = a2[j] = d4{0.0, 0.0, 0.0, 0.0};
+#if !(defined(MVF_DIAG) && (MVF_DIAG & 1))
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (q < p) {   // uniform
+#pragma unroll
+              for (int u = 0; u < E4; u += 2) {
+                const double a = ec[u] * xc[q], b = ec[u + 1] * xc[q];
+                const double* brow = Bs + ((4 * u + kq) * p + q) * n + i;
+                const double* crow = brow + 4 * p * n;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                  a1[j] = MFMA_F64(a, brow[j * 16], a1[j]);
+                  a2[j] = MFMA_F64(b, crow[j * 16], a2[j]);
+                }
+              }
+            }
+          }
+#endif
+#pragma unroll
+          for (int j = 0; j < NT; ++j) a1[j] += a2[j];
+          // leave the rows in the image: L and X by row owner (lane i), R and u by result layout (row kq + 4 t)
+          double* row = img + (wave * 16 + i) * W;
+#pragma unroll
+          for (int u = 0; u < E4; ++u) row[4 * u + kq] = ec[u];
+#pragma unroll
+          for (int q = 0; q < 8; q += 4)
+            if (q + kq < p) row[e + q + kq] = rowok ? (kq == 0 ? xc[q] : kq == 1 ? xc[q + 1] : kq == 2 ? xc[q + 2] : xc[q + 3]) : 0.0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            double* rrow = img + (wave * 16 + kq + 4 * t) * W;
+            double jv = 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              rrow[e + p + j * 16 + i] = rc[t][j];
+              jv += a1[j][t] * rc[t][j];
+            }
+            jv += __shfl_xor(jv, 8, 16);
+            jv += __shfl_xor(jv, 4, 16);
+            jv += __shfl_xor(jv, 2, 16);
+            jv += __shfl_xor(jv, 1, 16);
+            const double u_ = jv * hc[t];
+            if (i == 0) {
+              rrow[ucol] = u_;
+              pq_acc += jv * u_;
+            }
+          }
+        }
+      }
+    } else if (c >= 1) {
+      const int cc = c - 1;
+      const int nvalid = (int)min((int64_t)MVF_CH, s_end - s_begin - (int64_t)cc * MVF_CH);
+      const double* img = img0 + (cc & 1) * MVF_CH * W;
+#if defined(MVF_DIAG) && (MVF_DIAG & 2)
+      const int steps = 0;
+#else
+      const int steps = (nvalid + 3) >> 2;
+#endif
+#pragma unroll 2
+      for (int ks = 0; ks < steps; ++ks) {
+        const double* row = img + (ks * 4 + kq) * W;
+        const double us = row[ucol];
+        double av[MT], bv[TW];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) av[u] = row[u * 16 + i] * us;
+#pragma unroll
+        for (int v = 0; v < TW; ++v) bv[v] = row[oX[v]] * row[oR[v]];
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+          for (int v = 0; v < TW; ++v) acc[u][v] = MFMA_F64(av[u], bv[v], acc[u][v]);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave >= 4) {
+    double* dst = partial + (int64_t)blockIdx.x * D;
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+      for (int v = 0; v < TW; ++v)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int l = u * 16 + kq + 4 * t;
+          const int col = ((wave - 4) * TW + v) * 16 + i;
+          if (col < N) dst[(int64_t)l * N + col] = acc[u][v][t];
+        }
+  }
+  const double pq = block_sum_512(pq_acc, red);
+  if (tid == 0) pq_part[blockIdx.x] = pq;
+}
+
+// Second half of a fused conjugate-gradient iteration: q = sum of the workgroup partials (16 outputs x
+// 16 slab groups per workgroup, fixed order), alpha = rho / <p, q> from the partial dots, x += alpha p,
+// r -= alpha q, and this workgroup's part of the new <r, r>.
+__global__ __launch_bounds__(256) void cg_reduce_update_kernel(const double* __restrict__ partial, int nslabs,
+                                                                int64_t D, const double* __restrict__ pq_part,
+                                                                double* __restrict__ cgst, int it,
+                                                                double* __restrict__ x, double* __restrict__ r,
+                                                                const double* __restrict__ pvec,
+                                                                double* __restrict__ rho_part) {
+  __shared__ double part[16][17];
+  __shared__ double red[4];
+  if (cgst[3] != 0.0) return;
+  double a = 0.0;
+  for (int k = threadIdx.x; k < nslabs; k += 256) a += pq_part[k];
+  const double alpha = cgst[it & 1] / block_sum_256(a, red);
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
+  const int64_t src = idx < D ? idx : D - 1;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = g;
+  for (; k + 48 < nslabs; k += 64) {
+    a0 += partial[(int64_t)k * D + src];
+    a1 += partial[(int64_t)(k + 16) * D + src];
+    a2 += partial[(int64_t)(k + 32) * D + src];
+    a3 += partial[(int64_t)(k + 48) * D + src];
+  }
+  for (; k < nslabs; k += 16) a0 += partial[(int64_t)k * D + src];
+  part[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0) {
+    double rr = 0.0;
+    if (idx < D) {
+      double q = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q += part[j][o];
+      x[idx] += alpha * pvec[idx];
+      const double rn = r[idx] - alpha * q;
+      r[idx] = rn;
+      rr = rn * rn;
+    }
+    rr += __shfl_xor(rr, 8, 16);
+    rr += __shfl_xor(rr, 4, 16);
+    rr += __shfl_xor(rr, 2, 16);
+    rr += __shfl_xor(rr, 1, 16);
+    if (o == 0) rho_part[blockIdx.x] = rr;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cgst[4] += 1.0;
+}
+
+struct MvfDims {
+  int ok, E4, TW, W, nwg, nrp;
+  int64_t slab_len, D;
+  size_t lds;
+};
+
+static MvfDims mvf_dims(int64_t S, int C, int rl, int p, int rr) {
+  MvfDims d;
+  d.ok = 0;
+  if (C != 1 || rl != rr || (rl != 16 && rl != 32) || p < 1 || p > 8 || S < 1) return d;
+  const int e = rl;
+  d.E4 = e / 4;
+  d.TW = (p * (e / 16) + 3) / 4;
+  d.W = (2 * e + p + 2) | 1;   // odd: sample rows of the image fall on different banks both row-wise and column-wise
+  d.D = (int64_t)e * p * e;
+  int64_t nwg = (S + MVF_CH - 1) / MVF_CH;
+  if (nwg > 256) nwg = 256;   // one workgroup (eight waves, most of the LDS) per compute unit
+  d.nwg = (int)nwg;
+  d.slab_len = round_up64((S + nwg - 1) / nwg, 4);
+  d.nrp = (int)((d.D + 15) / 16);
+  d.lds = ((size_t)d.D + (size_t)2 * MVF_CH * d.W) * sizeof(double);
+  d.ok = d.lds <= 150 * 1024;
+  return d;
+}
+
+typedef void (*mvf_fn_t)(const double*, const double*, const double*, const double*, const double*, const double*, double*,
+                         double*, const double*, int, int, int64_t, int, int64_t, int, double*, double*);
+template <int MODE>
+static mvf_fn_t mvf_pick(int E4, int TW) {
+  if (E4 == 4) {
+    switch (TW) {
+      case 1: return matvec_fused_kernel<4, 1, MODE>;
+      default: return matvec_fused_kernel<4, 2, MODE>;
+    }
+  }
+  switch (TW) {
+    case 1: return matvec_fused_kernel<8, 1, MODE>;
+    case 2: return matvec_fused_kernel<8, 2, MODE>;
+    case 3: return matvec_fused_kernel<8, 3, MODE>;
+    default: return matvec_fused_kernel<8, 4, MODE>;
+  }
+}
+
+static bool mvf_timing_begin(hipStream_t st);
+static void mvf_timing_end(hipStream_t st);
+
+static int mvf_launch(int mode, const MvfDims& d, const double* L, const double* X, const double* R, const double* H,
+                      const double* vsrc, const double* pold, double* pnew, double* cgst, const double* rho_part, int it,
+                      int64_t S, int p, double* partial, double* pq_part, hipStream_t st) {
+  mvf_fn_t fn = mode ? mvf_pick<1>(d.E4, d.TW) : mvf_pick<0>(d.E4, d.TW);
+  static mvf_fn_t allowed[16];   // dynamic LDS above 64 KiB has to be allowed once per kernel
+  static int nallowed = 0;
+  bool seen = false;
+  for (int k = 0; k < nallowed; ++k) seen |= allowed[k] == fn;
+  if (!seen) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return TTK_ELAUNCH;
+    if (nallowed < 16) allowed[nallowed++] = fn;
+  }
+  const bool timed = mvf_timing_begin(st);
+  hipLaunchKernelGGL(fn, dim3((unsigned)d.nwg), dim3(512), d.lds, st, L, X, R, H, vsrc, pold, pnew, cgst, rho_part, d.nrp, it,
+                     S, p, d.slab_len, d.W, partial, pq_part);
+  if (timed) mvf_timing_end(st);
+  return ttk_launch_status();
+}
+
 // hu[s,d] = sum_c H[s,c,d] u[s,c]
 __global__ __launch_bounds__(256) void jvp_hess_kernel(const double* __restrict__ u, const double* __restrict__ H,
                                                         double* __restrict__ hu, int64_t S, int C) {
@@ -2546,6 +2915,14 @@ static const int kTimingPool = 512;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
 static bool g_ev_created = false, g_ev_armed = false;
 static int g_ev_count = 0;
+static int g_ev_which = 1;   // 1: the Gram kernel, 2: the fused matrix-free product kernel
+
+static bool mvf_timing_begin(hipStream_t st) {
+  const bool timed = g_ev_armed && g_ev_which == 2 && g_ev_count < kTimingPool;
+  if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
+  return timed;
+}
+static void mvf_timing_end(hipStream_t st) { (void)hipEventRecord(g_ev_stop[g_ev_count++], st); }
 
 // =======================================================================================
 // C ABI
@@ -2560,6 +2937,7 @@ int ttk_gram_timing(int enable) {
     g_ev_created = true;
   }
   g_ev_armed = enable != 0;
+  g_ev_which = enable == 2 ? 2 : 1;
   g_ev_count = 0;
   return TTK_OK;
 }
@@ -2684,7 +3062,7 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
                      rr, F);
   const size_t lds = (size_t)2 * d.bufd * sizeof(double);
   const unsigned grid = (unsigned)d.ngroups * (unsigned)d.nslabs;
-  const bool timed = g_ev_armed && g_ev_count < kTimingPool;
+  const bool timed = g_ev_armed && g_ev_which == 1 && g_ev_count < kTimingPool;
   if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
   if (C == 1)
     hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds, st, (const double*)F, S, C, rl, p, rr, sym_left,
@@ -2890,6 +3268,52 @@ int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const 
   if (!ws) return TTK_ELAUNCH;
   // every slab partial and every GL entry is written before it is read: nothing has to start at zero
   return rhs_run(L, X, R, g, b, S, C, rl, p, rr, accumulate, d, ws, (hipStream_t)stream);
+}
+
+int64_t ttk_matvec_fused_ws_bytes(int64_t S, int C, int rl, int p, int rr) {
+  const MvfDims d = mvf_dims(S, C, rl, p, rr);
+  if (!d.ok) return TTK_EINVAL;
+  return ((int64_t)d.nwg * d.D + d.nwg + d.nrp) * (int64_t)sizeof(double);
+}
+
+int ttk_matvec_fused_f64(const double* L, const double* X, const double* R, const double* H, const double* v, double* out,
+                         int64_t S, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L || !X || !R || !v || !out || !ws) return TTK_EINVAL;
+  const MvfDims d = mvf_dims(S, 1, rl, p, rr);
+  if (!d.ok) return TTK_EINVAL;
+  if (ws_bytes < ttk_matvec_fused_ws_bytes(S, 1, rl, p, rr)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  double* pq_part = partial + (int64_t)d.nwg * d.D;
+  int rc = mvf_launch(0, d, L, X, R, H, v, nullptr, nullptr, nullptr, nullptr, 0, S, p, partial, pq_part, st);
+  if (rc != TTK_OK) return rc;
+  if (d.nwg > 32)
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((d.D + 15) / 16)), dim3(256), 0, st, (const double*)partial,
+                       d.nwg, d.D, d.D, out, 0);
+  else
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((d.D + 255) / 256)), dim3(256), 0, st, (const double*)partial,
+                       d.nwg, d.D, d.D, out, 0);
+  return ttk_launch_status();
+}
+
+int ttk_cg_fused_iter_f64(const double* L, const double* X, const double* R, const double* H, double* x, double* r,
+                          double* pbuf, double* state, int it, int64_t S, int rl, int p, int rr, void* ws,
+                          int64_t ws_bytes, void* stream) {
+  if (!L || !X || !R || !x || !r || !pbuf || !state || !ws || it < 0) return TTK_EINVAL;
+  const MvfDims d = mvf_dims(S, 1, rl, p, rr);
+  if (!d.ok) return TTK_EINVAL;
+  if (ws_bytes < ttk_matvec_fused_ws_bytes(S, 1, rl, p, rr)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  double* pq_part = partial + (int64_t)d.nwg * d.D;
+  double* rho_part = pq_part + d.nwg;
+  double* pnew = pbuf + (int64_t)(it & 1) * d.D;
+  const double* pold = pbuf + (int64_t)((it + 1) & 1) * d.D;
+  int rc = mvf_launch(1, d, L, X, R, H, r, pold, pnew, state, rho_part, it, S, p, partial, pq_part, st);
+  if (rc != TTK_OK) return rc;
+  hipLaunchKernelGGL(cg_reduce_update_kernel, dim3((unsigned)d.nrp), dim3(256), 0, st, (const double*)partial, d.nwg, d.D,
+                     (const double*)pq_part, state, it, x, r, (const double*)pnew, rho_part);
+  return ttk_launch_status();
 }
 
 int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, void* stream) {

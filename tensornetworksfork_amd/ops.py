@@ -243,9 +243,58 @@ def jvp(L, X, R, H, v):
     return hu
 
 
+_mvf_ws = {}
+
+
+def matvec_fused_supported(S, C, rl, p, rr):
+    """Whether the one-pass product kernel takes these extents (one output, square bonds of 16 / 32, p <= 8)."""
+    return int(_lib.lib().ttk_matvec_fused_ws_bytes(int(S), int(C), int(rl), int(p), int(rr))) > 0
+
+
+def _mvf_workspace(S, rl, p, rr, device):
+    nbytes = int(_lib.lib().ttk_matvec_fused_ws_bytes(S, 1, rl, p, rr))
+    key = (device, nbytes)
+    ws = _mvf_ws.get(key)
+    if ws is None:
+        _mvf_ws.clear()
+        ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=device)
+        _mvf_ws[key] = ws
+    return ws, nbytes
+
+
 def matvec(L, X, R, H, v):
-    """(J^T H J) v without forming the Gram matrix."""
+    """(J^T H J) v without forming the Gram matrix: one fused pass where the shape allows it, else
+    the Jacobian-vector product followed by the transposed one."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    if S > 0 and matvec_fused_supported(S, C, rl, p, rr):
+        ws, nbytes = _mvf_workspace(S, rl, p, rr, L.device)
+        out = torch.empty((rl, p, rr), dtype=F64, device=L.device)
+        rc = _lib.lib().ttk_matvec_fused_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
+                                             _chk(H, "H", (S, 1, 1)), _chk(v, "v", (rl, p, rr)), out.data_ptr(),
+                                             S, rl, p, rr, ws.data_ptr(), nbytes, _stream(L))
+        _lib.check(rc, "ttk_matvec_fused_f64")
+        return out
     return rhs(L, X, R, jvp(L, X, R, H, v))
+
+
+class CGFused:
+    """scipy.sparse.linalg.cg on the operator of one Khatri-Rao term, two launches per iteration and no
+    host read inside the loop (see ttk_cg_fused_iter_f64)."""
+
+    def __init__(self, L, X, R, H):
+        S, C, rl = L.shape
+        self.dims = (S, rl, X.shape[1], R.shape[1])
+        self.ptrs = (_chk(L, "L"), _chk(X, "X", (S, X.shape[1])), _chk(R, "R", (S, R.shape[1])), _chk(H, "H", (S, 1, 1)))
+        self.keep = (L, X, R, H)
+        self.ws, self.nbytes = _mvf_workspace(S, rl, X.shape[1], R.shape[1], L.device)
+
+    def iterate(self, x, r, pbuf, state, it):
+        S, rl, p, rr = self.dims
+        rc = _lib.lib().ttk_cg_fused_iter_f64(*self.ptrs, _chk(x, "x"), _chk(r, "r"), _chk(pbuf, "pbuf"),
+                                              _chk(state, "state"), int(it), S, rl, p, rr, self.ws.data_ptr(),
+                                              self.nbytes, _stream(x))
+        _lib.check(rc, "ttk_cg_fused_iter_f64")
 
 
 def solve_rhs(b, w=None, scale=None, ridge=0.0):
@@ -320,8 +369,9 @@ def axpy(a, x, y, sign=1.0):
 
 
 def gram_timing(enable):
-    """Arm / disarm HIP-event timing of the Gram kernel (see ttk_gram_timing)."""
-    _lib.check(_lib.lib().ttk_gram_timing(1 if enable else 0), "ttk_gram_timing")
+    """Arm / disarm HIP-event timing of the Gram kernel (True / 1) or of the fused matrix-free
+    product kernel (2); see ttk_gram_timing."""
+    _lib.check(_lib.lib().ttk_gram_timing(int(enable)), "ttk_gram_timing")
 
 
 def gram_timing_read(max_n=512):

@@ -227,6 +227,16 @@ class LocalProblem:
             return self.rhs(hu)
         return mv
 
+    def cg_fused(self, H):
+        """ops.CGFused for this problem's operator when the one-pass product kernel takes it (one
+        Khatri-Rao term, one output, square bonds of 16 / 32, few features), else None."""
+        if self.terms is None or len(self.terms) != 1:
+            return None
+        L, X, R = self.terms[0]
+        if not (L.is_cuda and ops.matvec_fused_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1])):
+            return None
+        return ops.CGFused(L.contiguous(), X.contiguous(), R.contiguous(), H)
+
     def slice(self, lo, hi):
         """The same problem restricted to samples [lo, hi) (first-axis views, no copies)."""
         if self.J is not None:

@@ -17,8 +17,8 @@ import torch
 from .. import ops
 from .engine import ChainEngine
 from .node import TensorNode
-from .solvers import (_cholesky_solve, _host_solver, _scipy_kind, cg_solve, lanczos_solve,  # noqa: F401
-                      minres_solve)
+from .solvers import (_cholesky_solve, _host_solver, _scipy_kind, cg_solve, cg_solve_fused,  # noqa: F401
+                      lanczos_solve, minres_solve)
 
 _LEGACY_KWARGS = ("eps_r", "delta", "D_reg_fn")  # accepted and ignored: stale call sites pass them
 
@@ -670,7 +670,11 @@ class TensorNetwork:
                     loss_callback(lossv)
                 mv = self._matvec_fn(d, lp, H)
                 if kind == 'cg':
-                    sol, _ = cg_solve(mv, -b, warm.get(node), max_iter, tol)
+                    fused = None if d.sharded else lp.cg_fused(H)   # (a sharded product needs an all-reduce in between)
+                    if fused is not None:
+                        sol, _ = cg_solve_fused(fused, mv, -b, warm.get(node), max_iter, tol)
+                    else:
+                        sol, _ = cg_solve(mv, -b, warm.get(node), max_iter, tol)
                 elif kind == 'minres':
                     sol, _ = minres_solve(mv, -b, warm.get(node), max_iter, tol)
                 else:

@@ -80,6 +80,32 @@ def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     return xk, (0 if st[2] != 0.0 else maxiter)
 
 
+def cg_solve_fused(fused, matvec, b, x0, maxiter, rtol, check_every=20):
+    """cg_solve on an operator that ops.CGFused takes: every iteration is two launches (the product
+    with the direction update in its prologue; the slab reduction with the x / r updates behind it),
+    all scalars stay on the device."""
+    shape = b.shape
+    bf = b.reshape(-1)
+    if x0 is None:
+        xk = torch.zeros_like(bf)
+        r = bf.clone()
+    else:
+        xk = x0.reshape(-1).clone()
+        r = bf - matvec(xk.reshape(shape)).reshape(-1)
+    pbuf = torch.zeros(2 * bf.numel(), dtype=b.dtype, device=b.device)
+    bb = ops.dot(bf, bf)
+    state = torch.stack((torch.zeros_like(bb), ops.dot(r, r), rtol * bb.sqrt(), torch.zeros_like(bb), torch.zeros_like(bb)))
+    state = state.contiguous()
+    for it in range(maxiter):
+        fused.iterate(xk, r, pbuf, state, it)
+        if (it + 1) % check_every == 0 and it + 1 < maxiter and state[3].item() != 0.0:
+            break
+    st = state.tolist() + [bb.item()]
+    if st[5] == 0.0:
+        return torch.zeros_like(b), 0
+    return xk.reshape(shape), (0 if st[3] != 0.0 else maxiter)
+
+
 def minres_solve(matvec, b, x0, maxiter, rtol, check_every=10):
     """MINRES (Paige & Saunders) following scipy.sparse.linalg.minres (SciPy 1.15
     _isolve/minres.py) without shift or preconditioner, in float64 on the device.  Every scalar of

@@ -129,6 +129,10 @@ def rhs_supported(S, C, rl, p, rr):
     return True
 
 
+def matvec_fused_supported(S, C, rl, p, rr):
+    return False
+
+
 def gl(g, L):
     return torch.einsum('sc,scl->sl', g, L)
 
@@ -224,7 +228,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
+         "matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
 
 
 def install(monkeypatch):

@@ -26,6 +26,9 @@ SHAPES = [  # S, C, rl, p, rr
     (5000, 3, 8, 3, 40), (40999, 1, 8, 4, 64), (2001, 2, 16, 2, 17), (70001, 1, 32, 6, 32), (9000, 1, 40, 3, 8),
     # bonds of 16 / 32 with at most 8 features: operands held in registers, both directions, 1..4 column tiles
     (4099, 3, 16, 8, 48), (3001, 2, 32, 5, 16), (1500, 1, 64, 3, 32), (2500, 1, 16, 7, 32), (777, 1, 32, 8, 16),
+    # one output, square bonds of 16 / 32, at most 8 features: the one-pass matrix-free product (ragged slabs,
+    # a single partial chunk, one feature, the widest core)
+    (3001, 1, 16, 5, 16), (1000, 1, 32, 8, 32), (9, 1, 16, 1, 16), (16411, 1, 32, 3, 32), (33, 1, 16, 8, 16),
 ]
 
 
@@ -347,3 +350,35 @@ def test_krylov_solvers_match_scipy(n, maxiter, rtol):
             x, info = solve(lambda v: Ad @ v, b.to(dev), None if x0 is None else x0.to(dev), maxiter, rtol)
             assert (info == 0) == (info_r == 0), (name, info, info_r)
             assert G.rel_err(x, torch.tensor(np.asarray(x_r))) < 1e-7, (name, n, x0 is None)
+
+
+@gpu
+@pytest.mark.parametrize("S,rl,p", [(54000, 32, 6), (2000, 16, 4), (40, 32, 8)])
+def test_cg_fused_matches_unfused(S, rl, p):
+    """The two-launch conjugate-gradient iteration (product with the direction update in its prologue,
+    slab reduction with the x / r updates behind it) against the same recurrence run kernel by kernel
+    and against SciPy on the explicit Gram matrix, cold and warm started, converging and not."""
+    import numpy as np
+    import scipy.sparse.linalg as spla
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor.solvers import cg_solve, cg_solve_fused
+    dev = _dev()
+    L, X, R = _rand((S, 1, rl), 1).to(dev), _rand((S, p), 2).to(dev), _rand((S, rl), 3).to(dev)
+    H = (_rand((S, 1, 1), 4).abs() + 0.5).to(dev)
+    b = _rand((rl, p, rl), 5).to(dev)
+    assert ops.matvec_fused_supported(S, 1, rl, p, rl)
+    fused = ops.CGFused(L, X, R, H)
+    mv = lambda v: ops.rhs(L, X, R, ops.jvp(L, X, R, H, v.reshape(rl, p, rl))).reshape(v.shape)   # noqa: E731
+    A = ops.gram_expand(ops.gram(L, H, X, R, sym=True)).cpu().numpy() if rl * p * rl <= 2048 else None
+    for x0 in (None, _rand((rl, p, rl), 6).to(dev)):
+        # (with fewer samples than unknowns the operator is singular and long runs blow up chaotically)
+        for maxiter, rtol in ((7, 1e-30), (60, 1e-3)) if S >= rl * p * rl else ((5, 1e-30),):
+            x_f, info_f = cg_solve_fused(fused, mv, b, x0, maxiter, rtol)
+            x_u, info_u = cg_solve(mv, b, x0, maxiter, rtol)
+            assert info_f == info_u
+            assert G.rel_err(x_f, x_u) < 1e-8, (S, rl, p, maxiter)
+            if A is not None:
+                x_r, info_r = spla.cg(A, b.reshape(-1).cpu().numpy(), x0=None if x0 is None else x0.reshape(-1).cpu().numpy(),
+                                      maxiter=maxiter, rtol=rtol)
+                assert (info_f == 0) == (info_r == 0)
+                assert G.rel_err(x_f.reshape(-1), torch.tensor(np.asarray(x_r))) < 1e-7
