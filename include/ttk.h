@@ -223,6 +223,49 @@ int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* 
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, void* stream);
 
+/* ---- sites with many features (conv-featurised / operator columns) and explicit Jacobian rows ----
+ *
+ * ttk_conv_feature_{f64,f32}: G[ab, row] = sum_x X[row, x] F[x, ab] for rows = (sample, patch): the
+ * contraction of the input node with the filter node of a conv column (tensor/layers.py:839-872, done
+ * by contract_with inside compute_stacks in the reference).  X (rows, px) float64 or float32 (a float32
+ * data set, image_convolution_lanczos_CIFAR10.py, is read as it is), F (px, nab), G (nab, rows).
+ *
+ * ttk_gemm_rows_f64: T (M,N) (+)= A (M,K) B, rows = samples.  bmode 0: B (K,N) row-major; 1: B(k,(l,r)) =
+ * core[l,k,r] with core (rl,K,rr), N = rl*rr: T[s,(l,r)] = sum_p X[s,p] core[l,p,r], the feature
+ * contraction done first at a site with many features; 2: B(k,col) = Bt[col,k], Bt (N,K) row-major.
+ *
+ * ttk_env_right_dense_f64: ttk_env_step_right_f64 for sites with many features (any p, rr <= 64): the
+ * same result by contracting the features first (C p / (C + p) times fewer operations), T never stored.
+ *
+ * ttk_lcontract_f64: out[s,c,j] (+)= sum_l L[s,c,l] T[s,l,j], T (S,rl,n): second stage of the left
+ * environment step of such a site, and M = L . (A . R) of a feature node's Jacobian.
+ *
+ * ttk_patch_contract_{f64,f32}: J[s,c,x] (+)= sum_p M[s,c,p] X[s,p,x] written at
+ * J + s*jstride_s + c*jstride_c + x*xstride: Jacobian rows of a conv filter node (compute_jacobian_stack,
+ * tensor/network.py:101-113, for a node C_k).
+ *
+ * ttk_gemm_tn_f64: Cm (D1,D2) (+)= A^T B with A (n,D1), B (n,D2): the Gram matrix J^T (H J) of a local
+ * problem given by explicit rows (get_A_b, tensor/network.py:207,212, for a sum of Khatri-Rao terms).
+ *
+ * ttk_dense_scale_f64 / ttk_chol_prepare_dense_f64: solve_system's scaling and ridge shift
+ * (tensor/network.py:296-316) from a dense (D,D) matrix into the storage of ttk_chol_solve_f64. */
+int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream);
+int ttk_conv_feature_f32(const float* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream);
+int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
+                      int accumulate, void* stream);
+int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
+                            int rr, int accumulate, void* stream);
+int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
+                      void* stream);
+int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
+                           int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
+int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
+                           int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
+int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream);
+int ttk_dense_scale_f64(const double* A, int D, double* scale, void* stream);
+int ttk_chol_prepare_dense_f64(const double* A, int D, const double* scale, double ridge, const double* b, const double* w,
+                               void* chol_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

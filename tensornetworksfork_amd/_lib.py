@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTK_LIB_PATH") or os.path.join(_HERE, "libttk.so")   # (override: diagnostic builds)
 SRC_PATH = os.path.join(_HERE, "csrc", "ttk.hip")
+SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "ttk_dense.hip")]
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 _c_dp = ctypes.c_void_p
@@ -52,6 +53,16 @@ SIGNATURES = {
     "ttk_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_cg_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_minres_update_f64": (_int, [_c_dp] * 8 + [_i64, _c_dp]),
+    "ttk_conv_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
+    "ttk_conv_feature_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
+    "ttk_gemm_rows_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
+    "ttk_env_right_dense_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_lcontract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_patch_contract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
+    "ttk_patch_contract_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
+    "ttk_gemm_tn_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
+    "ttk_dense_scale_f64": (_int, [_c_dp, _int, _c_dp, _c_dp]),
+    "ttk_chol_prepare_dense_f64": (_int, [_c_dp, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),
     "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _c_dp]),
 }
 
@@ -66,10 +77,10 @@ def build(force=False, verbose=False):
     """Compile csrc/ttk.hip for gfx950 into libttk.so (cross-compiles without a GPU)."""
     import subprocess
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "ttk.h"))):
+            [os.path.getmtime(s) for s in SRC_PATHS] + [os.path.getmtime(os.path.join(INCLUDE_DIR, "ttk.h"))]):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE_DIR,
-           "-o", LIB_PATH, SRC_PATH]
+           "-o", LIB_PATH] + SRC_PATHS
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

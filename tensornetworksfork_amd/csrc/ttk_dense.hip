@@ -1,0 +1,519 @@
+// ttk_dense.hip -- gfx950 kernels for columns with many features (conv-featurised and operator
+// columns: tens of patches per site) and for local problems given by explicit Jacobian rows.
+//
+// A site with P >= 16 features contracts the features FIRST: T[s,(l,r)] = sum_p X[s,p] core[l,p,r]
+// is a plain GEMM shared by all outputs of a sample (rows = samples, K = P), and the two
+// environments follow as small per-sample contractions: C p / (C + p) times fewer FLOPs than the
+// three-factor Khatri-Rao rows.  Everything here is fp64 on v_mfma_f64_16x16x4_f64 (operand lane
+// map as in ttk.hip: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result
+// register t of lane l is D[(l >> 4) + 4 t][l & 15]).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ttk.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+static inline int dense_status() { return hipGetLastError() == hipSuccess ? TTK_OK : TTK_ELAUNCH; }
+
+// ---------------------------------------------------------------------------------------
+// G[a,b][s,p] = sum_x X[s,p,x] F[a,x,b]: the feature vector of a conv column (tensor/layers.py:839-872:
+// the edge between the input node X_k and the filter node C_k).  HBM-bound: X is read once, in
+// contiguous blocks of rows staged through LDS (row stride px + (px even): conflict-free row walks).
+// TI = float reads a float32 data set (image_convolution_lanczos_CIFAR10.py) without a float64 copy.
+// ---------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void conv_feature_kernel(const TI* __restrict__ X, const double* __restrict__ F,
+                                                            double* __restrict__ G, int64_t rows, int px, int nab, int RB) {
+  extern __shared__ double smem[];
+  const int pxs = px | 1;
+  double* Fs = smem;                 // [px][nab]
+  double* Xs = Fs + px * nab;        // [RB][pxs], RB <= 256 rows per workgroup
+  const int tid = threadIdx.x;
+  for (int k = tid; k < px * nab; k += 256) Fs[k] = F[k];   // F (a, x, b) -> Fs[x][a*cb + b] is done by the host layout
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int nrows = (int)min((int64_t)RB, rows - r0);
+  const TI* src = X + r0 * px;
+  const int total = nrows * px;
+  for (int k0 = tid; k0 < RB * px; k0 += 256 * 8) {
+    TI v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[min(k0 + 256 * u, total - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 256 * u;
+      if (k < total) {
+        const int r = k / px;
+        Xs[r * pxs + (k - r * px)] = (double)v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    const double* xr = Xs + tid * pxs;
+    for (int ab = 0; ab < nab; ++ab) {
+      double acc = 0.0;
+      for (int x = 0; x < px; ++x) acc += xr[x] * Fs[x * nab + ab];
+      G[(int64_t)ab * rows + r0 + tid] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row GEMM with an on-the-fly right operand and two epilogues.
+//   T[m, col] = sum_k A[m,k] B(k, col),  A (M,K) row-major, rows = samples.
+// BMODE 0: B (K,N) row-major.  BMODE 1: B(k,(l,r)) = core[l,k,r], core (rl,K,rr): the feature
+// contraction of a site.  BMODE 2: B(k,col) = Bt[col,k], Bt (N,K) row-major.
+// EPI 0 (TPL = 4, LB = 1): T is stored (M,N), 64 columns per pass.
+// EPI 1 (BMODE 1 only): z[m,l] = sum_r T[m,(l,r)] Rv[m,r] is stored instead (the right-environment step
+// of a site with many features, or the first half of J v).  A pass then covers LB consecutive l, each
+// with its rr columns padded to TPL 16-wide tiles, so every MFMA tile lies inside one l and the row
+// dot is a 16-lane shuffle sum; T never exists.
+// A workgroup owns 64 rows (one 16-row tile per wave): the A tile ([k][row], stride 65; staged once when
+// K fits one chunk) and the B block of a pass ([k][col], stride 16 mod 32 doubles: the four k of an
+// operand read fall on different bank halves) go through LDS in nkc equal K chunks of at most 64.
+// ---------------------------------------------------------------------------------------
+template <int BMODE, int EPI, int TPL, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                           double* __restrict__ out, int64_t M, int K, int N, int rl,
+                                                           int rr, const double* __restrict__ Rv, int accumulate, int kch) {
+  extern __shared__ double smem[];
+  constexpr int NT = TPL * LB;
+  constexpr int bw = NT * 16;          // columns per pass
+  constexpr int bs = bw + 16 + (bw & 16);   // row stride of Bs, 16 mod 32
+  double* As = smem;                   // [kch][65]
+  double* Bs = smem + kch * 65;        // [kch][bs]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int mrows = (int)min((int64_t)64, M - m0);
+  const int nkc = (K + kch - 1) / kch;
+  const int nblocks = EPI == 1 ? (rl + LB - 1) / LB : (N + 63) / 64;
+  auto stage_a = [&](int kc0, int kcn) {
+    // A[m0 + r][kc0 + k], coalesced along k, stored transposed
+    for (int k0 = tid; k0 < 64 * kcn; k0 += 256 * 4) {
+      double v[4];
+      int rr_[4], kk_[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(k0 + 256 * u, 64 * kcn - 1);
+        rr_[u] = idx / kcn;
+        kk_[u] = idx - rr_[u] * kcn;
+        v[u] = A[(m0 + min(rr_[u], mrows - 1)) * K + kc0 + kk_[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + 256 * u < 64 * kcn) As[kk_[u] * 65 + rr_[u]] = rr_[u] < mrows ? v[u] : 0.0;
+    }
+    const int kp = (kcn + 3) & ~3;
+    for (int idx = tid; idx < (kp - kcn) * 64; idx += 256) As[(kcn + idx / 64) * 65 + (idx & 63)] = 0.0;
+  };
+  auto stage_b = [&](int blk, int kc0, int kcn) {
+    // eight loads in flight per thread (clamped sources, zero selected afterwards), then the LDS writes
+    const int kp = (kcn + 3) & ~3;
+    const int total = kp * bw;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      double v[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(i0 + 256 * u, total - 1);
+        const int k = idx / bw, c = idx - k * bw;
+        const int kk = kc0 + min(k, kcn - 1);
+        int64_t src;
+        if (EPI == 1) {
+          const int lsub = c / (TPL * 16), r = c - lsub * (TPL * 16), l = blk * LB + lsub;
+          ok[u] = k < kcn && r < rr && l < rl;
+          src = ((int64_t)min(l, rl - 1) * K + kk) * rr + min(r, rr - 1);
+        } else {
+          const int col = blk * 64 + c;
+          const int cc = min(col, N - 1);
+          ok[u] = k < kcn && col < N;
+          if (BMODE == 0) src = (int64_t)kk * N + cc;
+          else if (BMODE == 1) { const int l = cc / rr; src = ((int64_t)l * K + kk) * rr + (cc - l * rr); }
+          else src = (int64_t)cc * K + kk;
+        }
+        v[u] = B[src];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 256 * u;
+        if (idx < total) {
+          const int k = idx / bw, c = idx - k * bw;
+          Bs[k * bs + c] = ok[u] ? v[u] : 0.0;
+        }
+      }
+    }
+  };
+  if (nkc == 1) stage_a(0, K);
+  for (int blk = 0; blk < nblocks; ++blk) {
+    d4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int kc0 = kc * kch, kcn = min(kch, K - kc0);
+      __syncthreads();   // everybody is done with the previous Bs (and As)
+      if (nkc > 1) stage_a(kc0, kcn);
+      stage_b(blk, kc0, kcn);
+      __syncthreads();
+      const int ksteps = (kcn + 3) >> 2;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const double a = As[(ks * 4 + kq) * 65 + wave * 16 + i];
+        const double* brow = Bs + (ks * 4 + kq) * bs + i;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, brow[j * 16], acc[j]);
+      }
+    }
+    if (EPI == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = wave * 16 + kq + 4 * t;
+          const int col = blk * 64 + j * 16 + i;
+          if (r < mrows && col < N) {
+            double* o = out + (m0 + r) * N + col;
+            *o = accumulate ? *o + acc[j][t] : acc[j][t];
+          }
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = wave * 16 + kq + 4 * t;
+        const double* rrow = Rv + (m0 + min(r, mrows - 1)) * rr;
+        double rvv[TPL];
+#pragma unroll
+        for (int j = 0; j < TPL; ++j) rvv[j] = (j * 16 + i < rr) ? rrow[min(j * 16 + i, rr - 1)] : 0.0;
+#pragma unroll
+        for (int lsub = 0; lsub < LB; ++lsub) {
+          double z = 0.0;
+#pragma unroll
+          for (int j = 0; j < TPL; ++j) z += acc[lsub * TPL + j][t] * rvv[j];
+          z += __shfl_xor(z, 8, 16);
+          z += __shfl_xor(z, 4, 16);
+          z += __shfl_xor(z, 2, 16);
+          z += __shfl_xor(z, 1, 16);
+          const int l = blk * LB + lsub;
+          if (i == 0 && r < mrows && l < rl) {
+            double* o = out + (m0 + r) * rl + l;
+            *o = accumulate ? *o + z : z;
+          }
+        }
+      }
+    }
+  }
+}
+
+// K chunk (a multiple of 4, at most 64) and dynamic LDS of a gemm_rows launch with `bw` columns per pass
+static int gemm_rows_chunk(int K) {
+  const int nkc = (K + 63) / 64;
+  return (((K + nkc - 1) / nkc) + 3) & ~3;
+}
+static size_t gemm_rows_lds(int kch, int bw) { return (size_t)kch * (65 + bw + 16 + (bw & 16)) * sizeof(double); }
+
+// out[s,c,j] (+)= sum_l L[s,c,l] T[s,l,j]: the output index of the left environment applied to the
+// feature-contracted core (second stage of the left step of a site with many features; also
+// M[s,c,u] = L . (A . R) of a feature node's Jacobian).  HBM-bound on T.  A workgroup takes whole
+// samples (as many as fit 256 threads at one thread per (s, j), or one sample in several passes over j):
+// their L rows go through LDS, T is read coalesced along j.
+__global__ __launch_bounds__(256) void lcontract_kernel(const double* __restrict__ L, const double* __restrict__ T,
+                                                         double* __restrict__ out, int64_t S, int C, int rl, int n,
+                                                         int spb, int accumulate) {
+  extern __shared__ double Ls[];   // [spb][C * rl]
+  const int64_t s0 = (int64_t)blockIdx.x * spb;
+  const int ns = (int)min((int64_t)spb, S - s0);
+  const int CL = C * rl;
+  for (int k = threadIdx.x; k < ns * CL; k += 256) Ls[k] = L[s0 * CL + k];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < ns * n; idx += 256) {
+    const int sl = idx / n, j = idx - sl * n;
+    const double* Lrow = Ls + sl * CL;
+    const double* Ts = T + (s0 + sl) * (int64_t)rl * n + j;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      double acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+      for (int l = 0; l < rl; ++l) {
+        const double t = Ts[(int64_t)l * n];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += Lrow[min(c0 + c, C - 1) * rl + l] * t;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c0 + c < C) {
+          double* o = out + ((s0 + sl) * C + c0 + c) * n + j;
+          *o = accumulate ? *o + acc[c] : acc[c];
+        }
+    }
+  }
+}
+
+// J[s,c,x] (+)= sum_p Mv[s,c,p] X[s,p,x], written with row stride jstride and column stride xstride (the
+// Jacobian rows of a conv filter node C_k[a,x,b] sit at J[s,c,a,x,b]).  One workgroup per sample: X[s]
+// and Mv[s] through LDS, one thread per (c, x).  HBM-bound on X.
+template <typename TI>
+__global__ __launch_bounds__(256) void patch_contract_kernel(const double* __restrict__ Mv, const TI* __restrict__ X,
+                                                              double* __restrict__ J, int C, int P, int px,
+                                                              int64_t jstride_s, int64_t jstride_c, int64_t xstride,
+                                                              int accumulate) {
+  extern __shared__ double smem[];
+  double* Xs = smem;            // [P][px]
+  double* Ms = Xs + P * px;     // [C][P]
+  const int64_t s = blockIdx.x;
+  const TI* xs = X + s * (int64_t)P * px;
+  for (int k = threadIdx.x; k < P * px; k += 256) Xs[k] = (double)xs[k];
+  const double* ms = Mv + s * (int64_t)C * P;
+  for (int k = threadIdx.x; k < C * P; k += 256) Ms[k] = ms[k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < C * px; o += 256) {
+    const int c = o / px, x = o - c * px;
+    double acc = 0.0;
+    for (int pp = 0; pp < P; ++pp) acc += Ms[c * P + pp] * Xs[pp * px + x];
+    double* dst = J + s * jstride_s + c * jstride_c + x * xstride;
+    *dst = accumulate ? *dst + acc : acc;
+  }
+}
+
+// Cm[D1 x D2] (+)= A^T B, A (n, D1), B (n, D2) row-major: the dense Gram J^T (H J) of a local problem
+// given by explicit Jacobian rows (several Khatri-Rao terms: tensor/network.py:207,212 evaluated on
+// rows).  64 x 64 output tiles, 4 waves as 2 x 2 of 32 x 32 wave tiles; both operands are k-major in
+// memory, so a 16-row slice of each is copied as it is into LDS ([k][col], stride 65), the next slice
+// travelling in registers meanwhile.
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                         double* __restrict__ Cm, int64_t n, int D1, int D2,
+                                                         int accumulate) {
+  __shared__ double As[16][65];
+  __shared__ double Bs[16][65];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int sk = tid >> 4, sc = (tid & 15) * 4;      // staged element (k = sk, columns sc .. sc + 3)
+  d4 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+  double pa[4], pb[4];
+  auto fetch = [&](int64_t k0) {
+    const int64_t kk = min(k0 + sk, n - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pa[e] = A[kk * D1 + min(r0 + sc + e, D1 - 1)];
+      pb[e] = B[kk * D2 + min(c0 + sc + e, D2 - 1)];
+    }
+  };
+  fetch(0);
+  for (int64_t k0 = 0; k0 < n; k0 += 16) {
+    if (k0) __syncthreads();
+    const bool live = k0 + sk < n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      As[sk][sc + e] = (live && r0 + sc + e < D1) ? pa[e] : 0.0;
+      Bs[sk][sc + e] = (live && c0 + sc + e < D2) ? pb[e] : 0.0;
+    }
+    __syncthreads();
+    if (k0 + 16 < n) fetch(k0 + 16);
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        af[u] = As[q + kq][wr * 32 + u * 16 + li];
+        bf[u] = Bs[q + kq][wc * 32 + u * 16 + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = MFMA_F64(af[u], bf[v], acc[u][v]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = r0 + wr * 32 + u * 16 + kq + 4 * t, c = c0 + wc * 32 + v * 16 + li;
+        if (r < D1 && c < D2) {
+          double* o = Cm + (int64_t)r * D2 + c;
+          *o = accumulate ? *o + acc[u][v][t] : acc[u][v][t];
+        }
+      }
+}
+
+// Dense matrix -> Cholesky storage of ttk_chol_solve_f64: lower triangle of A / scale + ridge I, identity
+// on the padded diagonal, zero elsewhere in the padded rows; scale[0] = mean |diag A| (1 if 0) is
+// computed by dense_scale_kernel first (solve_system's scaling, tensor/network.py:296-302).
+__global__ __launch_bounds__(1024) void dense_scale_kernel(const double* __restrict__ A, int D, double* __restrict__ scale) {
+  __shared__ double wsum[16];
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < D; k += 1024) acc += fabs(A[(int64_t)k * D + k]);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += wsum[k];
+    t /= (double)D;
+    scale[0] = (t == 0.0) ? 1.0 : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_to_chol_kernel(const double* __restrict__ A, int D, const double* __restrict__ scale,
+                                                             double ridge, double* __restrict__ aug, int ld) {
+  const int row = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col > row || col >= ld) return;
+  double v;
+  if (row >= D) {
+    v = (row == col) ? 1.0 : 0.0;
+  } else {
+    v = A[(int64_t)row * D + col];
+    if (scale) v = v / scale[0];
+    if (row == col) v += ridge;
+  }
+  aug[(int64_t)row * ld + col] = v;
+}
+
+// rows of X a workgroup of conv_feature_kernel stages (its LDS image stays below 60 KiB)
+static int conv_feature_rows(int px, int nab) {
+  const int64_t room = 60 * 1024 / 8 - (int64_t)px * nab;
+  int64_t rb = room / (px | 1);
+  if (rb > 256) rb = 256;
+  return (int)rb;
+}
+
+extern "C" {
+
+int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream) {
+  if (!X || !F || !G || rows < 1 || px < 1 || nab < 1) return TTK_EINVAL;
+  const int RB = conv_feature_rows(px, nab);
+  if (RB < 1) return TTK_EINVAL;
+  const size_t lds = ((size_t)px * nab + (size_t)RB * (px | 1)) * sizeof(double);
+  hipLaunchKernelGGL(conv_feature_kernel<double>, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, (hipStream_t)stream,
+                     X, F, G, rows, px, nab, RB);
+  return dense_status();
+}
+
+int ttk_conv_feature_f32(const float* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream) {
+  if (!X || !F || !G || rows < 1 || px < 1 || nab < 1) return TTK_EINVAL;
+  const int RB = conv_feature_rows(px, nab);
+  if (RB < 1) return TTK_EINVAL;
+  const size_t lds = ((size_t)px * nab + (size_t)RB * (px | 1)) * sizeof(double);
+  hipLaunchKernelGGL(conv_feature_kernel<float>, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, (hipStream_t)stream,
+                     X, F, G, rows, px, nab, RB);
+  return dense_status();
+}
+
+int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
+                      int accumulate, void* stream) {
+  if (!A || !B || !T || M < 1 || K < 1 || N < 1 || bmode < 0 || bmode > 2) return TTK_EINVAL;
+  if (bmode == 1 && (rl < 1 || rr < 1 || (int64_t)rl * rr != N)) return TTK_EINVAL;
+  const dim3 grid((unsigned)((M + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  const int kch = gemm_rows_chunk(K);
+  const size_t lds = gemm_rows_lds(kch, 64);
+  const double* none = nullptr;
+  if (bmode == 0)
+    hipLaunchKernelGGL((gemm_rows_kernel<0, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
+  else if (bmode == 1)
+    hipLaunchKernelGGL((gemm_rows_kernel<1, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
+  else
+    hipLaunchKernelGGL((gemm_rows_kernel<2, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
+  return dense_status();
+}
+
+int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
+                            int rr, int accumulate, void* stream) {
+  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64) return TTK_EINVAL;
+  const dim3 grid((unsigned)((S + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  const int kch = gemm_rows_chunk(p);
+  const int N = rl * rr;
+  // (tiles per l) x (l per pass): six 16-wide tiles per pass where the bond allows it
+  switch ((rr + 15) / 16) {
+    case 1:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 1, 6>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+                         rr, R, accumulate, kch);
+      break;
+    case 2:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 2, 3>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+                         rr, R, accumulate, kch);
+      break;
+    case 3:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 3, 2>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+                         rr, R, accumulate, kch);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 4, 1>), grid, dim3(256), gemm_rows_lds(kch, 64), st, X, core, out, S, p, N, rl,
+                         rr, R, accumulate, kch);
+      break;
+  }
+  return dense_status();
+}
+
+int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
+                      void* stream) {
+  if (!L || !T || !out || S < 1 || C < 1 || rl < 1 || n < 1) return TTK_EINVAL;
+  int spb = n >= 256 ? 1 : 256 / n;
+  const int fit = (int)(48 * 1024 / ((size_t)C * rl * sizeof(double)));
+  if (fit < 1) return TTK_EINVAL;
+  if (spb > fit) spb = fit;
+  const size_t lds = (size_t)spb * C * rl * sizeof(double);
+  hipLaunchKernelGGL(lcontract_kernel, dim3((unsigned)((S + spb - 1) / spb)), dim3(256), lds, (hipStream_t)stream, L, T, out,
+                     S, C, rl, n, spb, accumulate);
+  return dense_status();
+}
+
+static int patch_contract_check(const void* M, const void* X, const void* J, int64_t S, int C, int P, int px) {
+  if (!M || !X || !J || S < 1 || C < 1 || P < 1 || px < 1) return TTK_EINVAL;
+  if (((size_t)P * px + (size_t)C * P) * sizeof(double) > 64 * 1024) return TTK_EINVAL;
+  return TTK_OK;
+}
+
+int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
+                           int64_t jstride_c, int64_t xstride, int accumulate, void* stream) {
+  const int rc = patch_contract_check(M, X, J, S, C, P, px);
+  if (rc != TTK_OK) return rc;
+  const size_t lds = ((size_t)P * px + (size_t)C * P) * sizeof(double);
+  hipLaunchKernelGGL(patch_contract_kernel<double>, dim3((unsigned)S), dim3(256), lds, (hipStream_t)stream, M, X, J, C, P, px,
+                     jstride_s, jstride_c, xstride, accumulate);
+  return dense_status();
+}
+
+int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
+                           int64_t jstride_c, int64_t xstride, int accumulate, void* stream) {
+  const int rc = patch_contract_check(M, X, J, S, C, P, px);
+  if (rc != TTK_OK) return rc;
+  const size_t lds = ((size_t)P * px + (size_t)C * P) * sizeof(double);
+  hipLaunchKernelGGL(patch_contract_kernel<float>, dim3((unsigned)S), dim3(256), lds, (hipStream_t)stream, M, X, J, C, P, px,
+                     jstride_s, jstride_c, xstride, accumulate);
+  return dense_status();
+}
+
+int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream) {
+  if (!A || !B || !Cm || n < 1 || D1 < 1 || D2 < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((D2 + 63) / 64), (unsigned)((D1 + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, A, B, Cm, n, D1, D2, accumulate);
+  return dense_status();
+}
+
+int ttk_dense_scale_f64(const double* A, int D, double* scale, void* stream) {
+  if (!A || !scale || D < 1) return TTK_EINVAL;
+  hipLaunchKernelGGL(dense_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A, D, scale);
+  return dense_status();
+}
+
+int ttk_chol_prepare_dense_f64(const double* A, int D, const double* scale, double ridge, const double* b, const double* w,
+                               void* chol_ws, void* stream) {
+  if (!A || !b || !chol_ws || D < 1) return TTK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (D + 63) / 64, ld = nb * 64;
+  double* aug = (double*)chol_ws;
+  hipLaunchKernelGGL(dense_to_chol_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)ld), dim3(256), 0, st, A, D, scale, ridge,
+                     aug, ld);
+  if (hipMemsetAsync(aug + (int64_t)ld * ld, 0, (size_t)64 * ld * sizeof(double), st) != hipSuccess) return TTK_ELAUNCH;
+  return ttk_solve_rhs_f64(b, w, scale, ridge, aug + (int64_t)ld * ld, (int64_t)D, stream);
+}
+
+}  // extern "C"

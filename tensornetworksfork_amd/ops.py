@@ -47,6 +47,9 @@ def env_step_left(E, X, core, out=None):
     return out
 
 
+DENSE_MIN_P = 16    # from this many features on a site contracts its features first (ttk_dense kernels)
+
+
 def env_step_right(R, X, core, out=None):
     """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl); with `out` given the result is added to it."""
     S, rr = R.shape
@@ -55,6 +58,15 @@ def env_step_right(R, X, core, out=None):
     if out is None:
         out = torch.empty((S, rl), dtype=F64, device=R.device)
     if S == 0:
+        return out
+    if p >= DENSE_MIN_P and rr == 1 and not acc:
+        # the last site: out[s,l] = (X . core[:, :, 0]^T)[s,l] R[s,0], a plain row GEMM and a row scaling
+        T = gemm_rows(X, core.reshape(rl, p), rl, bmode=2)
+        return kr_rows(T.unsqueeze(1), R, R.new_ones((S, 1))).reshape(S, rl)
+    if p >= DENSE_MIN_P and rr <= 64:
+        rc = _lib.lib().ttk_env_right_dense_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
+                                                _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
+        _lib.check(rc, "ttk_env_right_dense_f64")
         return out
     rc = _lib.lib().ttk_env_step_right_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
                                            _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
@@ -417,3 +429,103 @@ def gl(g, L):
     rc = _lib.lib().ttk_gl_f64(_chk(g, "g", (S, C)), _chk(L, "L"), out.data_ptr(), S, C, rl, _stream(L))
     _lib.check(rc, "ttk_gl_f64")
     return out
+
+
+def conv_feature(X, Fc):
+    """G (ca, cb, S, P) = X (S, P, px) . Fc (ca, px, cb); X float64 or float32 (read as it is)."""
+    S, P, px = X.shape
+    ca, _, cb = Fc.shape
+    G = torch.empty((ca, cb, S, P), dtype=F64, device=X.device)
+    if S == 0:
+        return G
+    if not X.is_cuda or not X.is_contiguous() or X.dtype not in (F64, torch.float32):
+        raise _lib.TTKError("conv_feature: expected a contiguous float64 / float32 CUDA/HIP tensor")
+    Fm = Fc.permute(1, 0, 2).reshape(px, ca * cb).contiguous()
+    fn = _lib.lib().ttk_conv_feature_f64 if X.dtype == F64 else _lib.lib().ttk_conv_feature_f32
+    _lib.check(fn(X.data_ptr(), _chk(Fm, "F"), G.data_ptr(), S * P, px, ca * cb, _stream(X)), "ttk_conv_feature")
+    return G
+
+
+def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None):
+    """T (M, N) (+)= A (M, K) B; bmode 0: B (K, N); 1: B = core (rl, K, rr), columns (l, r); 2: B (N, K) transposed."""
+    M, K = A.shape
+    acc = out is not None
+    T = out if acc else torch.empty((M, N), dtype=F64, device=A.device)
+    if M == 0:
+        return T
+    rc = _lib.lib().ttk_gemm_rows_f64(_chk(A, "A"), _chk(B, "B"), _chk(T, "T", (M, N)), M, K, int(N), int(bmode), int(rl),
+                                      int(rr), int(acc), _stream(A))
+    _lib.check(rc, "ttk_gemm_rows_f64")
+    return T
+
+
+def lcontract(L, T, out=None):
+    """out (S, C, n) (+)= sum_l L[s,c,l] T[s,l,:];  L (S, C, rl), T (S, rl, n)."""
+    S, C, rl = L.shape
+    n = T.shape[2]
+    acc = out is not None
+    o = out if acc else torch.empty((S, C, n), dtype=F64, device=L.device)
+    if S == 0:
+        return o
+    rc = _lib.lib().ttk_lcontract_f64(_chk(L, "L"), _chk(T, "T", (S, rl, n)), _chk(o, "out", (S, C, n)), S, C, rl, n,
+                                      int(acc), _stream(L))
+    _lib.check(rc, "ttk_lcontract_f64")
+    return o
+
+
+def env_step_left_dense(E, X, core, out=None):
+    """env_step_left for a site with many features: T = X . core (one GEMM shared by the C outputs),
+    then the left environment's output index."""
+    S, C, rl = E.shape
+    p, rr = core.shape[1], core.shape[2]
+    T = gemm_rows(X, core, rl * rr, bmode=1, rl=rl, rr=rr)
+    return lcontract(E, T.reshape(S, rl, rr), out=out)
+
+
+def patch_contract(M, X, J, a=0, b=0):
+    """J[s, c, a, :, b] = sum_p M[s,c,p] X[s,p,:]  for J (S, C, ca, px, cb) contiguous; X float64 / float32."""
+    S, C, P = M.shape
+    px = X.shape[2]
+    if not (J.is_contiguous() and J.dtype == F64 and J.is_cuda and X.is_contiguous() and X.dtype in (F64, torch.float32)):
+        raise _lib.TTKError("patch_contract: expected contiguous device tensors (J float64, X float64 / float32)")
+    ca, cb = J.shape[2], J.shape[4]
+    fn = _lib.lib().ttk_patch_contract_f64 if X.dtype == F64 else _lib.lib().ttk_patch_contract_f32
+    ptr = J.data_ptr() + 8 * (a * px * cb + b)
+    rc = fn(_chk(M, "M"), X.data_ptr(), ptr, S, C, P, px, C * ca * px * cb, ca * px * cb, cb, 0, _stream(M))
+    _lib.check(rc, "ttk_patch_contract")
+    return J
+
+
+def gemm_tn(A, B, out=None):
+    """(D1, D2) (+)= A^T B for A (n, D1), B (n, D2)."""
+    n, D1 = A.shape
+    D2 = B.shape[1]
+    acc = out is not None
+    Cm = out if acc else torch.empty((D1, D2), dtype=F64, device=A.device)
+    rc = _lib.lib().ttk_gemm_tn_f64(_chk(A, "A"), _chk(B, "B", (n, D2)), _chk(Cm, "C", (D1, D2)), n, D1, D2, int(acc),
+                                    _stream(A))
+    _lib.check(rc, "ttk_gemm_tn_f64")
+    return Cm
+
+
+def chol_solve_dense(A, b, w=None, ridge=0.0):
+    """x = -(A/scale + ridge I)^-1 (b/scale + ridge w), scale = mean |diag A| (1 if 0), by the blocked MFMA
+    Cholesky from a dense (D, D) matrix.  Returns (x (D,), info) like chol_solve_gram."""
+    D = A.shape[0]
+    nbytes = int(_lib.lib().ttk_chol_ws_bytes(D))
+    key = (A.device, D)
+    cw = _chol_ws.get(key)
+    if cw is None:
+        _chol_ws.clear()
+        cw = torch.empty((nbytes + 7) // 8, dtype=F64, device=A.device)
+        _chol_ws[key] = cw
+    st = _stream(A)
+    scale = torch.empty((), dtype=F64, device=A.device)
+    _lib.check(_lib.lib().ttk_dense_scale_f64(_chk(A, "A", (D, D)), D, scale.data_ptr(), st), "ttk_dense_scale_f64")
+    rc = _lib.lib().ttk_chol_prepare_dense_f64(A.data_ptr(), D, scale.data_ptr(), float(ridge), _chk(b, "b"),
+                                               None if w is None else _chk(w, "w"), cw.data_ptr(), st)
+    _lib.check(rc, "ttk_chol_prepare_dense_f64")
+    x = torch.empty((D,), dtype=F64, device=A.device)
+    info = torch.empty((), dtype=torch.int32, device=A.device)
+    _lib.check(_lib.lib().ttk_chol_solve_f64(cw.data_ptr(), D, x.data_ptr(), info.data_ptr(), st), "ttk_chol_solve_f64")
+    return x, info

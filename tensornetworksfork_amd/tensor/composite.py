@@ -168,7 +168,7 @@ class CPDEngine(EngineBase):
             core = self.canon(i)                                   # (C, R, p)
             f = self.cols[i]
             X = d.xs[i]
-            d.T[i] = (X @ core.reshape(f.C * f.R, f.p).T).reshape(d.S, f.C, f.R)   # plain library GEMM
+            d.T[i] = ops.gemm_rows(X, core.reshape(f.C * f.R, f.p).contiguous(), f.C * f.R, bmode=2).reshape(d.S, f.C, f.R)
         return d.T[i]
 
     def refresh(self, d):
@@ -228,7 +228,8 @@ class CPDEngine(EngineBase):
             k = self._index(node)
             f = self.cols[k]
             lo, hi = rows if rows is not None else (0, d.S)
-            T = (d.xs[k][lo:hi] @ core.reshape(f.C * f.R, f.p).T).reshape(hi - lo, f.C, f.R)
+            T = ops.gemm_rows(d.xs[k][lo:hi].contiguous(), core.reshape(f.C * f.R, f.p).contiguous(), f.C * f.R,
+                              bmode=2).reshape(hi - lo, f.C, f.R)
             W = self._others(d, k, False)
             P = T if W is None else T * W[lo:hi]
             return P.sum(dim=-1)

@@ -105,22 +105,8 @@ def pair_classes_many(Xs):
     return out
 
 
-def _xt_times(X, W, chunk=1024):
-    """X^T W for tall X (S,p), W (S,n): the library GEMM has no split over the long contraction, so
-    the samples are cut into chunks, multiplied as one batched GEMM and the partial products added."""
-    S = X.shape[0]
-    nk = S // chunk
-    if nk < 2:
-        return X.T @ W
-    S0 = nk * chunk
-    out = torch.bmm(X[:S0].reshape(nk, chunk, -1).transpose(1, 2), W[:S0].reshape(nk, chunk, -1)).sum(dim=0)
-    if S0 < S:
-        out = out + X[S0:].T @ W[S0:]
-    return out
-
-
 DENSE_ROWS_KERNEL_MAX_D = 128   # explicit Jacobian rows up to this width go through the Khatri-Rao kernels
-TWO_STAGE_MIN_P = 16    # from this many features on, J v and J^T g contract the features first (library GEMM)
+TWO_STAGE_MIN_P = 16    # from this many features on, J v and the environment steps contract the features first
 
 
 _ONES = {}
@@ -173,15 +159,13 @@ class LocalProblem:
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
         for (L, X, R) in self.terms:
-            # many features: with a bond of at least one MFMA tile the kernel still wins (measured 0.27 vs
-            # 0.31 ms at 50 features, bonds 24); a thin left bond wastes its tiles and goes the GEMM way
-            if X.shape[1] >= TWO_STAGE_MIN_P and not (
-                    L.shape[2] >= 16 and ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1])):
-                # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L : one plain GEMM over the samples
+            if not ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
+                # a sample row too wide for the right-hand-side kernel's LDS chunk: features last,
+                # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L, as one transposed product over the samples
                 S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
                 GL = ops.gl(g, L)                                                        # (S, rl)
                 W = ops.kr_rows(GL.unsqueeze(1), _ones_col(S, g.device), R).reshape(S, rl * rr)   # GL[s,l] R[s,r]
-                bt = _xt_times(X, W).reshape(X.shape[1], rl, rr).permute(1, 0, 2)
+                bt = ops.gemm_tn(X, W).reshape(X.shape[1], rl, rr).permute(1, 0, 2)
                 out = bt.contiguous() if out is None else out.add_(bt)
             else:
                 out = ops.rhs(L, X, R, g) if out is None else ops.rhs(L, X, R, g, out=out)
@@ -199,11 +183,9 @@ class LocalProblem:
         tmp = {}
         for (L, X, R) in self.terms:
             if X.shape[1] >= TWO_STAGE_MIN_P:
-                # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (plain GEMM shared by
-                # the C outputs of a sample), then the two environments: C*p/(C+p) times fewer FLOPs
-                S, rl, rr = L.shape[0], L.shape[2], R.shape[1]
-                T = X @ v.permute(1, 0, 2).reshape(X.shape[1], rl * rr)                 # (S, rl*rr)
-                z = ops.predict(T.reshape(S, rl, rr), R)                                 # (S, rl)
+                # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (one GEMM shared by the
+                # C outputs of a sample, never stored), then the two environments: C*p/(C+p) times fewer FLOPs
+                z = ops.env_step_right(R, X, v.contiguous())                             # (S, rl)
                 u = ops.predict(L, z) if u is None else ops.predict(L, z, out=u)         # (S, C)
                 continue
             key = id(R)                  # terms that share R share one environment-step buffer
@@ -268,8 +250,7 @@ class LocalProblem:
         return out
 
     def dense_gram(self, H, chunk_bytes=1 << 30):
-        """A (D,D) = sum_s J^T H J from explicit rows in sample chunks; the two large products
-        are plain library GEMMs (rocBLAS through torch.matmul)."""
+        """A (D,D) = sum_s J^T H J from explicit rows in sample chunks (ttk_gemm_tn_f64)."""
         D, C = self.D, self.C
         A = torch.zeros((D, D), dtype=F64, device=H.device)
         step = max(1, int(chunk_bytes // (8 * C * D)))
@@ -277,7 +258,7 @@ class LocalProblem:
             hi = min(self.S, lo + step)
             J = self.rows(lo, hi)
             HJ = ops.hess_left(H[lo:hi].contiguous(), J.contiguous())     # (n,C,D): sum_c H[s,c,d] J[s,c,:]
-            A.addmm_(J.reshape(-1, D).T, HJ.reshape(-1, D))
+            ops.gemm_tn(J.reshape(-1, D).contiguous(), HJ.reshape(-1, D), out=A)
         return A
 
 
@@ -596,7 +577,9 @@ class ChainEngine(EngineBase):
                 if tt.ndim != want:
                     raise ValueError(f"expected a {want}-d input (samples, features{', pixels' if want == 3 else ''}), "
                                      f"got shape {tuple(tt.shape)}")
-                done[id(t)] = ops.prep(tt)
+                # a float32 image set stays float32 (the kernels that read it convert on the fly)
+                keep32 = col.kind == "conv" and tt.dtype == torch.float32 and tt.is_cuda
+                done[id(t)] = tt.contiguous() if keep32 else ops.prep(tt)
             xs.append(done[id(t)])
         d = _Data(raw, xs, len(raw))
         d.sharded = shard is not None
@@ -627,21 +610,19 @@ class ChainEngine(EngineBase):
     # ------------------------------------------------------------------ features and environments
     def feats(self, d, k):
         """G_k: (ca, cb, S, p) feature vectors per feature-bond pair (a plain column: X itself).
-        The product with the feature node is one plain library GEMM."""
+        The product with the feature node is one streaming kernel (conv) / one row GEMM (operator)."""
         if d.G[k] is None:
             col = self.cols[k]
             X = d.xs[k]
             if col.kind == "plain":
                 d.G[k] = X.reshape(1, 1, *X.shape)
             elif col.kind == "conv":
-                Fc = self.canonF(k)                                   # (ca, px, cb)
-                S, p, px = X.shape
-                flat = X.reshape(S * p, px) @ Fc.permute(1, 0, 2).reshape(px, col.ca * col.cb)
-                d.G[k] = flat.reshape(S, p, col.ca, col.cb).permute(2, 3, 0, 1).contiguous()
+                d.G[k] = ops.conv_feature(X, self.canonF(k))          # (ca, px, cb) filter -> (ca, cb, S, p)
             else:
                 Fc = self.canonF(k)                                   # (ca, u, dd, cb)
                 u, dd = col.inner
-                flat = X @ Fc.permute(2, 0, 3, 1).reshape(dd, col.ca * col.cb * u)
+                Bm = Fc.permute(2, 0, 3, 1).reshape(dd, col.ca * col.cb * u).contiguous()
+                flat = ops.gemm_rows(X, Bm, col.ca * col.cb * u)
                 d.G[k] = flat.reshape(X.shape[0], col.ca, col.cb, u).permute(1, 2, 0, 3).contiguous()
         return d.G[k]
 
@@ -661,16 +642,14 @@ class ChainEngine(EngineBase):
         Lk, G = self.left(d, k), self.feats(d, k)
         ca, cb = G.shape[0], G.shape[1]
         rl, p, rr = core.shape
-        two_stage = p >= TWO_STAGE_MIN_P      # many features: contract them first (library GEMMs)
-        if two_stage:
-            cm = core.permute(1, 0, 2).reshape(p, rl * rr)
+        two_stage = p >= TWO_STAGE_MIN_P      # many features: contract them first
         outs = []
         for b in range(cb):
             o = None
             for a in range(ca):
                 if two_stage:
-                    t = torch.bmm(Lk[a], (G[a, b] @ cm).reshape(-1, rl, rr))
-                    o = t if o is None else o.add_(t)
+                    o = ops.env_step_left_dense(Lk[a], G[a, b], core) if o is None else \
+                        ops.env_step_left_dense(Lk[a], G[a, b], core, out=o)
                 else:
                     o = ops.env_step_left(Lk[a], G[a, b], core) if o is None else \
                         ops.env_step_left(Lk[a], G[a, b], core, out=o)
@@ -686,20 +665,12 @@ class ChainEngine(EngineBase):
             else:
                 Rn, G, core = self.right(d, k + 1), self.feats(d, k + 1), self.canonA(k + 1)
                 ca, cb = G.shape[0], G.shape[1]
-                rl, p, rr = core.shape
-                two_stage = p >= TWO_STAGE_MIN_P
-                if two_stage:
-                    cm = core.permute(1, 0, 2).reshape(p, rl * rr)
                 outs = []
                 for a in range(ca):
                     o = None
-                    for b in range(cb):
-                        if two_stage:
-                            T = (G[a, b] @ cm).reshape(-1, rl, rr)
-                            o = ops.predict(T, Rn[b]) if o is None else ops.predict(T, Rn[b], out=o)
-                        else:
-                            o = ops.env_step_right(Rn[b], G[a, b], core) if o is None else \
-                                ops.env_step_right(Rn[b], G[a, b], core, out=o)
+                    for b in range(cb):   # (a site with many features contracts them first inside the op)
+                        o = ops.env_step_right(Rn[b], G[a, b], core) if o is None else \
+                            ops.env_step_right(Rn[b], G[a, b], core, out=o)
                     outs.append(o)
                 d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
         return d.R[k]
@@ -753,7 +724,7 @@ class ChainEngine(EngineBase):
                 self.prefetch_pairs([self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"])
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
             return LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
-        # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (plain batched library GEMMs)
+        # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (a row GEMM, then the left environment's output index)
         #   conv filter    J[s,c,a,x,b]   = sum_patch M_ab[s,c,patch] X[s,patch,x]
         #   operator node  J[s,c,a,u,d,b] = M_ab[s,c,u] X[s,d]   (one Khatri-Rao term when a = b = 1)
         Fc = self.canonF(k)
@@ -762,8 +733,8 @@ class ChainEngine(EngineBase):
         A2 = core.reshape(col.rl * col.p, col.rr)
 
         def M(a, b):
-            U = (R[b] @ A2.T).reshape(S, col.rl, col.p)
-            return torch.bmm(L[a], U)                      # (S, C, p)
+            U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2).reshape(S, col.rl, col.p)
+            return ops.lcontract(L[a], U)                  # (S, C, p)
 
         if col.kind == "op" and ca == 1 and cb == 1:
             u, dd = col.inner
@@ -773,8 +744,9 @@ class ChainEngine(EngineBase):
         for b in range(cb):
             for a in range(ca):
                 if col.kind == "conv":
-                    J[:, :, a, :, b] = torch.bmm(M(a, b), X)                       # (S, C, px)
+                    ops.patch_contract(M(a, b), X, J, a, b)                       # J[:, :, a, :, b] = M . X
                 else:
-                    J[:, :, a, :, :, b] = M(a, b).unsqueeze(-1) * X.reshape(S, 1, 1, -1)
+                    u, dd = col.inner
+                    J[:, :, a, :, :, b] = ops.kr_rows(M(a, b), X, _ones_col(S, X.device)).reshape(S, C, u, dd)
         shape = (ca,) + col.inner + (cb,)
         return LocalProblem(S, C, shape, Fc, back, J=J.reshape(S, C, -1))

@@ -360,27 +360,35 @@ class TensorNetwork:
                 x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
             else:
                 x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
-                # the pivot check needs the host; it is settled after the gauge move has been queued
-                # (see _settle), so that nothing waits for the factorisation to drain first
-                if info.is_cuda:   # copied to pinned memory now, so that reading it does not wait for later kernels
-                    host = torch.empty((), dtype=info.dtype, pin_memory=True)
-                    host.copy_(info, non_blocking=True)
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    info = (host, ready)
-                self._pending = (info, [(n, n.tensor, list(n.dim_labels), list(n.left_labels), list(n.right_labels))
-                                        for n in dict.fromkeys(list(self.main_nodes) + [node])])
+                self._pend_pivot_check(info, node)
         else:
             A_f = front["A_f"]
-            scale = A_f.diagonal().abs().mean()
-            scale = torch.where(scale == 0, torch.ones_like(scale), scale)
-            A_f.div_(scale)
-            if ridge:
-                A_f.diagonal().add_(ridge)
-            rhs = ops.solve_rhs(b, core if ridged else None, scale, ridge).reshape(-1)
-            x = torch.linalg.solve(A_f, rhs) if m in ('exact', 'ridge_exact') else _cholesky_solve(A_f, rhs)
+            if m in ('exact', 'ridge_exact'):
+                scale = A_f.diagonal().abs().mean()
+                scale = torch.where(scale == 0, torch.ones_like(scale), scale)
+                A_f.div_(scale)
+                if ridge:
+                    A_f.diagonal().add_(ridge)
+                rhs = ops.solve_rhs(b, core if ridged else None, scale, ridge).reshape(-1)
+                x = torch.linalg.solve(A_f, rhs)
+            else:   # scaling, ridge shift and the blocked Cholesky of the dense matrix, all on the device
+                x, info = ops.chol_solve_dense(A_f, b.reshape(-1).contiguous(),
+                                               core.reshape(-1).contiguous() if ridged else None, ridge)
+                self._pend_pivot_check(info, node)
         node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return total
+
+    def _pend_pivot_check(self, info, node):
+        """The pivot check of a Cholesky needs the host; it is settled after the gauge move has been
+        queued (see _settle), so that nothing waits for the factorisation to drain first."""
+        if info.is_cuda:   # copied to pinned memory now, so that reading it does not wait for later kernels
+            host = torch.empty((), dtype=info.dtype, pin_memory=True)
+            host.copy_(info, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            info = (host, ready)
+        self._pending = (info, [(n, n.tensor, list(n.dim_labels), list(n.left_labels), list(n.right_labels))
+                                for n in dict.fromkeys(list(self.main_nodes) + [node])])
 
     def _settle(self):
         """Host-side check of the last Cholesky: on a non-positive pivot the nodes are put back as they

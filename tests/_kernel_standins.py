@@ -129,6 +129,50 @@ def rhs_supported(S, C, rl, p, rr):
     return True
 
 
+def conv_feature(X, Fc):
+    return torch.einsum('spx,axb->absp', X.to(F64), Fc).contiguous()
+
+
+def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None):
+    if bmode == 0:
+        T = A @ B
+    elif bmode == 1:
+        T = torch.einsum('sk,lkr->slr', A, B).reshape(A.shape[0], N)
+    else:
+        T = A @ B.T
+    return T if out is None else out.add_(T)
+
+
+def lcontract(L, T, out=None):
+    r = torch.einsum('scl,slj->scj', L, T)
+    return r if out is None else out.add_(r)
+
+
+def env_step_left_dense(E, X, core, out=None):
+    return env_step_left(E, X, core, out=out)
+
+
+def patch_contract(M, X, J, a=0, b=0):
+    J[:, :, a, :, b] = torch.einsum('scp,spx->scx', M, X.to(F64))
+    return J
+
+
+def gemm_tn(A, B, out=None):
+    r = A.T @ B
+    return r if out is None else out.add_(r)
+
+
+def chol_solve_dense(A, b, w=None, ridge=0.0):
+    s = A.diagonal().abs().mean()
+    s = torch.where(s == 0, torch.ones_like(s), s)
+    M = A / s + ridge * torch.eye(A.shape[0], dtype=F64)
+    Lc, info = torch.linalg.cholesky_ex(M)
+    if int(info) != 0:
+        return torch.zeros(A.shape[0], dtype=F64), info.to(torch.int32)
+    x = torch.cholesky_solve(solve_rhs(b, w, s, ridge).unsqueeze(-1), Lc).squeeze(-1)
+    return x, info.to(torch.int32)
+
+
 def matvec_fused_supported(S, C, rl, p, rr):
     return False
 
@@ -228,7 +272,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
 
 
 def install(monkeypatch):

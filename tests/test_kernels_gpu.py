@@ -382,3 +382,77 @@ def test_cg_fused_matches_unfused(S, rl, p):
                                       maxiter=maxiter, rtol=rtol)
                 assert (info_f == 0) == (info_r == 0)
                 assert G.rel_err(x_f.reshape(-1), torch.tensor(np.asarray(x_r))) < 1e-7
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", [(300, 9, 24, 50, 24), (1000, 3, 48, 65, 48), (77, 1, 5, 130, 7), (4099, 2, 9, 17, 64),
+                                         (64, 4, 16, 16, 16), (130, 9, 1, 33, 20)])
+def test_many_feature_kernels(S, C, rl, p, rr):
+    """Sites with many features (conv columns): right / left environment steps with the features
+    contracted first, the plain row GEMM in its three operand layouts, and the per-sample
+    contraction with the left environment, against einsum on the CPU (ragged row tiles, K above
+    one 64-chunk, bonds that are no multiple of the 16-wide MFMA tile)."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    E, X, core, R = _rand((S, C, rl), 1), _rand((S, p), 2), _rand((rl, p, rr), 3), _rand((S, rr), 4)
+    Ed, Xd, cd, Rd = E.to(dev), X.to(dev), core.to(dev), R.to(dev)
+    assert p >= ops.DENSE_MIN_P
+    z = ops.env_step_right(Rd, Xd, cd)
+    z_r = torch.einsum('sr,sp,lpr->sl', R, X, core)
+    assert G.rel_err(z, z_r) < TOL
+    base = _rand((S, rl), 5)
+    assert G.rel_err(ops.env_step_right(Rd, Xd, cd, out=base.to(dev)), base + z_r) < TOL
+    out_r = torch.einsum('scl,sp,lpr->scr', E, X, core)
+    assert G.rel_err(ops.env_step_left_dense(Ed, Xd, cd), out_r) < TOL
+    base = _rand((S, C, rr), 6)
+    assert G.rel_err(ops.env_step_left_dense(Ed, Xd, cd, out=base.to(dev)), base + out_r) < TOL
+    T_r = torch.einsum('sp,lpr->slr', X, core).reshape(S, rl * rr)
+    assert G.rel_err(ops.gemm_rows(Xd, cd, rl * rr, bmode=1, rl=rl, rr=rr), T_r) < TOL
+    Bm = _rand((p, 70), 7)
+    assert G.rel_err(ops.gemm_rows(Xd, Bm.to(dev), 70), X @ Bm) < TOL
+    assert G.rel_err(ops.gemm_rows(Xd, Bm.T.contiguous().to(dev), 70, bmode=2), X @ Bm) < TOL
+    Tt = _rand((S, rl, 37), 8)
+    assert G.rel_err(ops.lcontract(Ed, Tt.to(dev)), torch.einsum('scl,slj->scj', E, Tt)) < TOL
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,P,px,ca,cb,C", [(500, 50, 17, 1, 1, 9), (333, 65, 49, 1, 1, 9), (90, 10, 5, 2, 3, 4), (1, 3, 2, 1, 2, 1)])
+def test_conv_feature_and_filter_rows(dtype, S, P, px, ca, cb, C):
+    """The two kernels that read the raw image patches (float64, or float32 as the CIFAR script holds
+    them): feature vector G = X . F and the filter node's Jacobian rows J = M . X."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    X = _rand((S, P, px), 1).to(dtype)
+    Fc = _rand((ca, px, cb), 2)
+    Gd = ops.conv_feature(X.to(dev), Fc.to(dev))
+    assert G.rel_err(Gd, torch.einsum('spx,axb->absp', X.to(torch.float64), Fc)) < TOL
+    Mv = _rand((S, C, P), 3)
+    J = torch.full((S, C, ca, px, cb), 7.0, dtype=torch.float64, device=dev)
+    ref = torch.full((S, C, ca, px, cb), 7.0, dtype=torch.float64)
+    for a in range(ca):
+        for b in range(cb):
+            if (a + b) % 2 == 0 or ca * cb == 1:
+                ops.patch_contract(Mv.to(dev), X.to(dev), J, a, b)
+                ref[:, :, a, :, b] = torch.einsum('scp,spx->scx', Mv, X.to(torch.float64))
+    assert G.rel_err(J, ref) < TOL
+
+
+@gpu
+@pytest.mark.parametrize("n,D1,D2", [(5000, 17, 17), (333, 130, 70), (64, 64, 64), (1, 3, 5), (2049, 200, 200)])
+def test_gemm_tn_and_dense_cholesky(n, D1, D2):
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    A, B = _rand((n, D1), 1), _rand((n, D2), 2)
+    assert G.rel_err(ops.gemm_tn(A.to(dev), B.to(dev)), A.T @ B) < TOL
+    base = _rand((D1, D2), 3)
+    assert G.rel_err(ops.gemm_tn(A.to(dev), B.to(dev), out=base.to(dev)), base + A.T @ B) < TOL
+    if D1 == D2:
+        Gm = A.T @ A + 0.01 * torch.eye(D1, dtype=torch.float64)
+        b, w = _rand((D1,), 4), _rand((D1,), 5)
+        x, info = ops.chol_solve_dense(Gm.to(dev), b.to(dev), w.to(dev), 0.5)
+        assert int(info.item()) == 0
+        x_r = O.solve_system(Gm, b, w, 'ridge_cholesky', 0.25)
+        assert G.rel_err(x, x_r) < 1e-9
+        x, info = ops.chol_solve_dense(Gm.to(dev), b.to(dev), None, -5.0)
+        assert int(info.item()) >= 1
