@@ -261,6 +261,7 @@ def main():
     if args.warmup > 0:
         run_updates(tn, F, y, F_val, y_val, args.warmup)
     ops.gram_timing(True)
+    tn._marks = []          # device events at the phase boundaries of every core update
     fence()
     t0 = time.perf_counter()
     val_rmse = run_updates(tn, F, y, F_val, y_val, args.steps, eps0=0.5)
@@ -268,6 +269,13 @@ def main():
     elapsed = time.perf_counter() - t0
     gram_ms = ops.gram_timing_read()
     ops.gram_timing(False)
+    marks, tn._marks = tn._marks, None
+    phase = {"gram_ms": 0.0, "comm_ms": 0.0, "solve_ms": 0.0}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        key = {("front", "gram"): "gram_ms", ("gram", "comm"): "comm_ms", ("pre", "solve"): "solve_ms"}.get((n0, n1))
+        if key:
+            phase[key] += e0.elapsed_time(e1)
+    phase = {k: v / args.steps for k, v in phase.items()}
     if dist is not None:
         tmax = torch.tensor([elapsed], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -296,6 +304,10 @@ def main():
         "metric": "dmrg_core_updates_per_sec", "value": ups, "unit": "core-updates/s",
         "samples_per_sec": ups * S_train, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "step_breakdown_ms": dict(phase, other_ms=elapsed / args.steps * 1e3 - sum(phase.values()),
+                                  what="this rank, per core update, from device events: Gram (pack + kernel + slab "
+                                       "reduction), exchange (one all-reduce of [compressed Gram | b]), scaled ridge "
+                                       "Cholesky solve (replicated on every rank), everything else"),
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg2 TNML tensor train: 16 sites, bond 32, polynomial degree 5 (p=6), 60000x16 synthetic "
                                "samples (54000 train / 6000 val); middle-site core updates (D=6144) via "

@@ -60,22 +60,44 @@ class Shard:
             out.append(first.setdefault(k, b))
         return None if out == list(range(n)) else out
 
-    def allreduce_gram_(self, ws):
-        """Sum of the compressed Gram over ranks.  With feature-pair classes only the representative
+    def allreduce_gram_(self, ws, b=None):
+        """Sum of the compressed Gram (and, in the same message, of the right-hand side `b`) over
+        ranks: ONE collective per core update.  With feature-pair classes only the representative
         slices G[:, rep, :] travel (packed, summed, copied back to every member of their class): at
         the headline shape 24.5 MB instead of 46.8 MB.  The classes must be the common ones
-        (common_pair_classes), or ranks would disagree about the message size."""
+        (common_pair_classes), or ranks would disagree about the message size.  Without classes
+        the message is the workspace itself: `b` rides in the scratch right behind the Gram."""
         G = ws.compressed
         rep = getattr(ws, "pair_rep", None)
-        if self.world == 1 or rep is None:
-            return self.allreduce_sum_(G)
+        if self.world == 1:
+            return G
+        nb = 0 if b is None else b.numel()
+        if rep is None:
+            buf = getattr(ws, "buf", None)
+            if nb and buf is not None and buf.numel() >= G.numel() + nb and buf.data_ptr() == G.data_ptr():
+                msg = buf[:G.numel() + nb]
+                msg[G.numel():].copy_(b.reshape(-1))
+                self.allreduce_sum_(msg)
+                b.copy_(msg[G.numel():].reshape(b.shape))
+            else:
+                self.allreduce_sum_(G)
+                if nb:
+                    self.allreduce_sum_(b)
+            return G
         nx = len(rep)
         reps = sorted(set(int(v) for v in rep))
         pos = {r: i for i, r in enumerate(reps)}
         G3 = G.view(-1, nx, G.numel() // (ws.mppad * nx))
-        packed = G3.index_select(1, torch.tensor(reps, device=G.device))
-        self.allreduce_sum_(packed)
+        npk = G3.shape[0] * len(reps) * G3.shape[2]
+        msg = torch.empty(npk + nb, dtype=G.dtype, device=G.device)
+        packed = msg[:npk].view(G3.shape[0], len(reps), G3.shape[2])
+        torch.index_select(G3, 1, torch.tensor(reps, device=G.device), out=packed)
+        if nb:
+            msg[npk:].copy_(b.reshape(-1))
+        self.allreduce_sum_(msg)
         torch.index_select(packed, 1, torch.tensor([pos[int(v)] for v in rep], device=G.device), out=G3)
+        if nb:
+            b.copy_(msg[npk:].reshape(b.shape))
         return G
 
     def broadcast_(self, t, src=0):

@@ -307,10 +307,12 @@ class TensorNetwork:
         sym = self._hessian_symmetric(H, sharded=d.sharded)
         if lp.compressed_gram(sym):
             # compressed symmetric Gram in the workspace, own Cholesky on it
+            self._mark("front")
             ws = self._engine.gram_ws(lp, H, sym, shard=self._shard if d.sharded else None)
+            self._mark("gram")
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
-                self._shard.allreduce_gram_(ws)
-                self._shard.allreduce_sum_(b)
+                self._shard.allreduce_gram_(ws, b)
+                self._mark("comm")
             front["ws"] = ws
             front["gen"] = ws.generation   # the workspace is shared: a later Gram into it outdates this front
         else:
@@ -359,7 +361,9 @@ class TensorNetwork:
                 A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=self._engine.dense_buffer(lp.D, b.device))
                 x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
             else:
+                self._mark("pre")
                 x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
+                self._mark("solve")
                 self._pend_pivot_check(info, node)
         else:
             A_f = front["A_f"]
@@ -377,6 +381,15 @@ class TensorNetwork:
                 self._pend_pivot_check(info, node)
         node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return total
+
+    def _mark(self, name):
+        """Phase marks for benchmarking: with `self._marks` set to a list, a device event is recorded
+        at the end of each phase of a core update (no effect, no cost otherwise)."""
+        marks = getattr(self, "_marks", None)
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
 
     def _pend_pivot_check(self, info, node):
         """The pivot check of a Cholesky needs the host; it is settled after the gauge move has been

@@ -58,8 +58,22 @@ def main():
         FakeWS.compressed = G.reshape(-1).clone()
         want = FakeWS.compressed.clone()
         sh.allreduce_sum_(want)
-        sh.allreduce_gram_(FakeWS)
-        ok &= bool(torch.equal(FakeWS.compressed, want))
+        bvec = torch.arange(5, dtype=torch.float64) * (sh.rank + 2)
+        bwant = bvec.clone()
+        sh.allreduce_sum_(bwant)
+        sh.allreduce_gram_(FakeWS, bvec)                 # the right-hand side rides in the same message
+        ok &= bool(torch.equal(FakeWS.compressed, want)) and bool(torch.equal(bvec, bwant))
+
+        class PlainWS:                                   # no classes: the workspace itself is the message
+            mppad, pair_rep = 6, None
+        PlainWS.buf = torch.zeros(6 * 5 * 7 + 40, dtype=torch.float64)
+        PlainWS.buf[:210] = torch.arange(210, dtype=torch.float64) * (sh.rank + 1)
+        PlainWS.compressed = PlainWS.buf[:210]
+        want = PlainWS.compressed.clone()
+        sh.allreduce_sum_(want)
+        bvec = torch.arange(5, dtype=torch.float64) * (sh.rank + 2)
+        sh.allreduce_gram_(PlainWS, bvec)
+        ok &= bool(torch.equal(PlainWS.compressed, want)) and bool(torch.equal(bvec, bwant))
     else:
         from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
         from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
