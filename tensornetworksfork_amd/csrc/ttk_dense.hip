@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void conv_feature_kernel(const TI* __restrict_
 // K fits one chunk) and the B block of a pass ([k][col], stride 16 mod 32 doubles: the four k of an
 // operand read fall on different bank halves) go through LDS in nkc equal K chunks of at most 64.
 // ---------------------------------------------------------------------------------------
+#define GR_NB 24   // prefetch registers per thread for a B block: 64 k x 96 columns / 256 threads
 template <int BMODE, int EPI, int TPL, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                            double* __restrict__ out, int64_t M, int K, int N, int rl,
@@ -82,88 +83,98 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
   constexpr int NT = TPL * LB;
   constexpr int bw = NT * 16;          // columns per pass
   constexpr int bs = bw + 16 + (bw & 16);   // row stride of Bs, 16 mod 32
-  double* As = smem;                   // [kch][65]
-  double* Bs = smem + kch * 65;        // [kch][bs]
+  const int Kp = (K + 3) & ~3;
+  double* As = smem;                   // [Kp][65]: the whole A tile, staged once
+  double* Bs = smem + Kp * 65;         // [kch][bs]: one K chunk of the B block of a pass
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * 64;
   const int mrows = (int)min((int64_t)64, M - m0);
   const int nkc = (K + kch - 1) / kch;
   const int nblocks = EPI == 1 ? (rl + LB - 1) / LB : (N + 63) / 64;
-  auto stage_a = [&](int kc0, int kcn) {
-    // A[m0 + r][kc0 + k], coalesced along k, stored transposed
-    for (int k0 = tid; k0 < 64 * kcn; k0 += 256 * 4) {
-      double v[4];
-      int rr_[4], kk_[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = min(k0 + 256 * u, 64 * kcn - 1);
-        rr_[u] = idx / kcn;
-        kk_[u] = idx - rr_[u] * kcn;
-        v[u] = A[(m0 + min(rr_[u], mrows - 1)) * K + kc0 + kk_[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (k0 + 256 * u < 64 * kcn) As[kk_[u] * 65 + rr_[u]] = rr_[u] < mrows ? v[u] : 0.0;
+  // The B block of step (blk, kc) travels in registers while the previous step is multiplied: loads with
+  // clamped sources in one batch, zero selected when the registers go to LDS.
+  double pb[GR_NB];
+  auto b_src = [&](int idx, int blk, int kc0, int kcn, bool& ok) -> int64_t {
+    const int k = idx / bw, c = idx - k * bw;
+    const int kk = kc0 + min(k, kcn - 1);
+    if (EPI == 1) {
+      const int lsub = c / (TPL * 16), r = c - lsub * (TPL * 16), l = blk * LB + lsub;
+      ok = k < kcn && r < rr && l < rl;
+      return ((int64_t)min(l, rl - 1) * K + kk) * rr + min(r, rr - 1);
     }
-    const int kp = (kcn + 3) & ~3;
-    for (int idx = tid; idx < (kp - kcn) * 64; idx += 256) As[(kcn + idx / 64) * 65 + (idx & 63)] = 0.0;
+    const int col = blk * 64 + c;
+    const int cc = min(col, N - 1);
+    ok = k < kcn && col < N;
+    if (BMODE == 0) return (int64_t)kk * N + cc;
+    if (BMODE == 1) {
+      const int l = cc / rr;
+      return ((int64_t)l * K + kk) * rr + (cc - l * rr);
+    }
+    return (int64_t)cc * K + kk;
   };
-  auto stage_b = [&](int blk, int kc0, int kcn) {
-    // eight loads in flight per thread (clamped sources, zero selected afterwards), then the LDS writes
-    const int kp = (kcn + 3) & ~3;
-    const int total = kp * bw;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-      double v[8];
-      bool ok[8];
+  auto fetch_b = [&](int step) {
+    const int blk = step / nkc, kc = step - blk * nkc;
+    const int kc0 = kc * kch, kcn = min(kch, K - kc0);
+    const int total = ((kcn + 3) & ~3) * bw;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = min(i0 + 256 * u, total - 1);
+    for (int u = 0; u < GR_NB; ++u) {
+      bool ok;
+      pb[u] = B[b_src(min(tid + 256 * u, total - 1), blk, kc0, kcn, ok)];
+    }
+  };
+  auto store_b = [&](int step) {
+    const int blk = step / nkc, kc = step - blk * nkc;
+    const int kc0 = kc * kch, kcn = min(kch, K - kc0);
+    const int total = ((kcn + 3) & ~3) * bw;
+#pragma unroll
+    for (int u = 0; u < GR_NB; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < total) {
+        bool ok;
+        (void)b_src(idx, blk, kc0, kcn, ok);
         const int k = idx / bw, c = idx - k * bw;
-        const int kk = kc0 + min(k, kcn - 1);
-        int64_t src;
-        if (EPI == 1) {
-          const int lsub = c / (TPL * 16), r = c - lsub * (TPL * 16), l = blk * LB + lsub;
-          ok[u] = k < kcn && r < rr && l < rl;
-          src = ((int64_t)min(l, rl - 1) * K + kk) * rr + min(r, rr - 1);
-        } else {
-          const int col = blk * 64 + c;
-          const int cc = min(col, N - 1);
-          ok[u] = k < kcn && col < N;
-          if (BMODE == 0) src = (int64_t)kk * N + cc;
-          else if (BMODE == 1) { const int l = cc / rr; src = ((int64_t)l * K + kk) * rr + (cc - l * rr); }
-          else src = (int64_t)cc * K + kk;
-        }
-        v[u] = B[src];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = i0 + 256 * u;
-        if (idx < total) {
-          const int k = idx / bw, c = idx - k * bw;
-          Bs[k * bs + c] = ok[u] ? v[u] : 0.0;
-        }
+        Bs[k * bs + c] = ok ? pb[u] : 0.0;
       }
     }
   };
-  if (nkc == 1) stage_a(0, K);
-  for (int blk = 0; blk < nblocks; ++blk) {
-    d4 acc[NT];
+  const int nsteps = nblocks * nkc;
+  if (nsteps > 0) fetch_b(0);
+  // A[m0 + r][k], coalesced along k, stored transposed; rows K..Kp are zero
+  for (int k0 = tid; k0 < 64 * K; k0 += 256 * 4) {
+    double v[4];
+    int rr_[4], kk_[4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < nkc; ++kc) {
-      const int kc0 = kc * kch, kcn = min(kch, K - kc0);
-      __syncthreads();   // everybody is done with the previous Bs (and As)
-      if (nkc > 1) stage_a(kc0, kcn);
-      stage_b(blk, kc0, kcn);
-      __syncthreads();
-      const int ksteps = (kcn + 3) >> 2;
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const double a = As[(ks * 4 + kq) * 65 + wave * 16 + i];
-        const double* brow = Bs + (ks * 4 + kq) * bs + i;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, brow[j * 16], acc[j]);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(k0 + 256 * u, 64 * K - 1);
+      rr_[u] = idx / K;
+      kk_[u] = idx - rr_[u] * K;
+      v[u] = A[(m0 + min(rr_[u], mrows - 1)) * K + kk_[u]];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + 256 * u < 64 * K) As[kk_[u] * 65 + rr_[u]] = rr_[u] < mrows ? v[u] : 0.0;
+  }
+  for (int idx = tid; idx < (Kp - K) * 64; idx += 256) As[(K + idx / 64) * 65 + (idx & 63)] = 0.0;
+  d4 acc[NT];
+  for (int step = 0; step < nsteps; ++step) {
+    const int blk = step / nkc, kc = step - blk * nkc;
+    const int kc0 = kc * kch, kcn = min(kch, K - kc0);
+    if (kc == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();   // everybody is done with the previous Bs
+    store_b(step);
+    __syncthreads();   // (the first time this also publishes As)
+    if (step + 1 < nsteps) fetch_b(step + 1);
+    const int ksteps = (kcn + 3) >> 2;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const double a = As[(kc0 + ks * 4 + kq) * 65 + wave * 16 + i];
+      const double* brow = Bs + (ks * 4 + kq) * bs + i;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, brow[j * 16], acc[j]);
+    }
+    if (kc + 1 < nkc) continue;
     if (EPI == 0) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -204,12 +215,16 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
   }
 }
 
-// K chunk (a multiple of 4, at most 64) and dynamic LDS of a gemm_rows launch with `bw` columns per pass
+// K chunk of the B block (a multiple of 4, at most 64) and dynamic LDS of a gemm_rows launch with `bw`
+// columns per pass (the whole A tile of 64 rows x K stays in LDS)
 static int gemm_rows_chunk(int K) {
   const int nkc = (K + 63) / 64;
   return (((K + nkc - 1) / nkc) + 3) & ~3;
 }
-static size_t gemm_rows_lds(int kch, int bw) { return (size_t)kch * (65 + bw + 16 + (bw & 16)) * sizeof(double); }
+static size_t gemm_rows_lds(int K, int kch, int bw) {
+  return ((size_t)((K + 3) & ~3) * 65 + (size_t)kch * (bw + 16 + (bw & 16))) * sizeof(double);
+}
+#define GEMM_ROWS_MAX_K 256   // 64 x K A tile + one B chunk stay below 160 KiB
 
 // out[s,c,j] (+)= sum_l L[s,c,l] T[s,l,j]: the output index of the left environment applied to the
 // feature-contracted core (second stage of the left step of a site with many features; also
@@ -383,6 +398,21 @@ static int conv_feature_rows(int px, int nab) {
   return (int)rb;
 }
 
+// dynamic LDS above 64 KiB (long K) has to be allowed once per kernel
+static bool gemm_rows_allow_lds() {
+  static int state = 0;   // 0 not tried, 1 ok, -1 failed
+  if (state == 0) {
+    const void* fns[] = {(const void*)gemm_rows_kernel<0, 0, 4, 1>, (const void*)gemm_rows_kernel<1, 0, 4, 1>,
+                         (const void*)gemm_rows_kernel<2, 0, 4, 1>, (const void*)gemm_rows_kernel<1, 1, 1, 6>,
+                         (const void*)gemm_rows_kernel<1, 1, 2, 3>, (const void*)gemm_rows_kernel<1, 1, 3, 2>,
+                         (const void*)gemm_rows_kernel<1, 1, 4, 1>};
+    state = 1;
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) state = -1;
+  }
+  return state == 1;
+}
+
 extern "C" {
 
 int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream) {
@@ -412,7 +442,9 @@ int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, in
   const dim3 grid((unsigned)((M + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
   const int kch = gemm_rows_chunk(K);
-  const size_t lds = gemm_rows_lds(kch, 64);
+  if (K > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  const size_t lds = gemm_rows_lds(K, kch, 64);
+  if (!gemm_rows_allow_lds()) return TTK_ELAUNCH;
   const double* none = nullptr;
   if (bmode == 0)
     hipLaunchKernelGGL((gemm_rows_kernel<0, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
@@ -425,7 +457,8 @@ int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, in
 
 int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
                             int rr, int accumulate, void* stream) {
-  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64) return TTK_EINVAL;
+  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  if (!gemm_rows_allow_lds()) return TTK_ELAUNCH;
   const dim3 grid((unsigned)((S + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
   const int kch = gemm_rows_chunk(p);
@@ -433,19 +466,19 @@ int ttk_env_right_dense_f64(const double* R, const double* X, const double* core
   // (tiles per l) x (l per pass): six 16-wide tiles per pass where the bond allows it
   switch ((rr + 15) / 16) {
     case 1:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 1, 6>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 1, 6>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
                          rr, R, accumulate, kch);
       break;
     case 2:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 2, 3>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 2, 3>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
                          rr, R, accumulate, kch);
       break;
     case 3:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 3, 2>), grid, dim3(256), gemm_rows_lds(kch, 96), st, X, core, out, S, p, N, rl,
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 3, 2>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
                          rr, R, accumulate, kch);
       break;
     default:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 4, 1>), grid, dim3(256), gemm_rows_lds(kch, 64), st, X, core, out, S, p, N, rl,
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 4, 1>), grid, dim3(256), gemm_rows_lds(p, kch, 64), st, X, core, out, S, p, N, rl,
                          rr, R, accumulate, kch);
       break;
   }

@@ -48,6 +48,7 @@ def env_step_left(E, X, core, out=None):
 
 
 DENSE_MIN_P = 16    # from this many features on a site contracts its features first (ttk_dense kernels)
+DENSE_MAX_P = 256   # ... up to what the row GEMM keeps in LDS (beyond: the streaming Khatri-Rao kernels)
 
 
 def env_step_right(R, X, core, out=None):
@@ -59,11 +60,11 @@ def env_step_right(R, X, core, out=None):
         out = torch.empty((S, rl), dtype=F64, device=R.device)
     if S == 0:
         return out
-    if p >= DENSE_MIN_P and rr == 1 and not acc:
+    if DENSE_MIN_P <= p <= DENSE_MAX_P and rr == 1 and not acc:
         # the last site: out[s,l] = (X . core[:, :, 0]^T)[s,l] R[s,0], a plain row GEMM and a row scaling
         T = gemm_rows(X, core.reshape(rl, p), rl, bmode=2)
         return kr_rows(T.unsqueeze(1), R, R.new_ones((S, 1))).reshape(S, rl)
-    if p >= DENSE_MIN_P and rr <= 64:
+    if DENSE_MIN_P <= p <= DENSE_MAX_P and rr <= 64:
         rc = _lib.lib().ttk_env_right_dense_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
                                                 _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
         _lib.check(rc, "ttk_env_right_dense_f64")

@@ -107,6 +107,7 @@ def pair_classes_many(Xs):
 
 DENSE_ROWS_KERNEL_MAX_D = 128   # explicit Jacobian rows up to this width go through the Khatri-Rao kernels
 TWO_STAGE_MIN_P = 16    # from this many features on, J v and the environment steps contract the features first
+TWO_STAGE_MAX_P = 256   # ... up to what the row GEMM keeps in LDS; beyond, the streaming Khatri-Rao kernels
 
 
 _ONES = {}
@@ -182,7 +183,7 @@ class LocalProblem:
         u = None
         tmp = {}
         for (L, X, R) in self.terms:
-            if X.shape[1] >= TWO_STAGE_MIN_P:
+            if TWO_STAGE_MIN_P <= X.shape[1] <= TWO_STAGE_MAX_P:
                 # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (one GEMM shared by the
                 # C outputs of a sample, never stored), then the two environments: C*p/(C+p) times fewer FLOPs
                 z = ops.env_step_right(R, X, v.contiguous())                             # (S, rl)
@@ -199,7 +200,7 @@ class LocalProblem:
 
     def matvec_fn(self, H):
         """v -> (J^T H J) v, canonical shape, never forming the Gram matrix."""
-        if self.terms is not None and len(self.terms) == 1 and self.terms[0][1].shape[1] < TWO_STAGE_MIN_P:
+        if self.terms is not None and len(self.terms) == 1 and not TWO_STAGE_MIN_P <= self.terms[0][1].shape[1] <= TWO_STAGE_MAX_P:
             L, X, R = self.terms[0]
             return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
@@ -642,7 +643,7 @@ class ChainEngine(EngineBase):
         Lk, G = self.left(d, k), self.feats(d, k)
         ca, cb = G.shape[0], G.shape[1]
         rl, p, rr = core.shape
-        two_stage = p >= TWO_STAGE_MIN_P      # many features: contract them first
+        two_stage = TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P      # many features: contract them first
         outs = []
         for b in range(cb):
             o = None
