@@ -3,7 +3,8 @@
 A node is a `torch.Tensor` plus one label per axis and a dict of edges to other
 nodes.  The network (tensor/network.py of this package) reads the labels to
 recognise the tensor-train chain and hands the raw device pointers to the HIP
-kernels; no contraction is performed by the node itself.
+kernels; the sweep methods never contract nodes pairwise.  `contract_with` /
+`contract_vertically` are kept for callers that use the graph API directly.
 """
 from collections import defaultdict
 
@@ -14,6 +15,43 @@ def _as_list(x):
     if x is None:
         return []
     return [x] if isinstance(x, str) else list(x)
+
+
+def _pair_contract(A, la, B, lb, contract, out_labels):
+    """sum over `contract` of A[la] B[lb] -> axes `out_labels`; labels in both operands that are not
+    contracted are batch axes.  Brought to (batch, M, K) x (batch, K, N): one row GEMM without batch
+    axes, one per-sample contraction kernel with them (float64 on the device, within the kernels'
+    LDS limits); torch.matmul otherwise (host tensors, other dtypes)."""
+    from .. import ops
+    size = {}
+    for t, labs in ((A, la), (B, lb)):
+        for n, lab in zip(t.shape, labs):
+            size[lab] = n
+    for lab in contract:                      # a label only one operand carries is simply summed away
+        if lab in la and lab not in lb:
+            A = A.sum(la.index(lab))
+            la = [x for x in la if x != lab]
+        elif lab in lb and lab not in la:
+            B = B.sum(lb.index(lab))
+            lb = [x for x in lb if x != lab]
+    K = [lab for lab in la if lab in lb and lab in contract]
+    batch = [lab for lab in la if lab in lb and lab not in contract]
+    M = [lab for lab in la if lab not in lb]
+    N = [lab for lab in lb if lab not in la]
+    prod = lambda labs: int(torch.tensor([size[x] for x in labs]).prod()) if labs else 1   # noqa: E731
+    Bt, Mt, Kt, Nt = prod(batch), prod(M), prod(K), prod(N)
+    A3 = A.permute([la.index(x) for x in batch + M + K]).reshape(Bt, Mt, Kt)
+    B3 = B.permute([lb.index(x) for x in batch + K + N]).reshape(Bt, Kt, Nt)
+    on_dev = A3.is_cuda and B3.is_cuda and A3.dtype == torch.float64 and B3.dtype == torch.float64
+    if on_dev and Bt == 1 and Kt <= ops.DENSE_MAX_P:
+        C3 = ops.gemm_rows(A3[0].contiguous(), B3[0].contiguous(), Nt).unsqueeze(0)
+    elif on_dev and Bt > 1 and Mt * Kt * 8 <= 48 * 1024:
+        C3 = ops.lcontract(A3.contiguous(), B3.contiguous())
+    else:
+        C3 = torch.matmul(A3, B3)
+    cur = batch + M + N
+    C = C3.reshape([size[x] for x in cur])
+    return C.permute([cur.index(x) for x in out_labels]) if cur != list(out_labels) else C
 
 
 class TensorNode:
@@ -60,8 +98,77 @@ class TensorNode:
         return label in self.left_labels or label in self.right_labels
 
     def contract_with(self, other_node, contract_labels=None):
-        raise NotImplementedError("generic pairwise contraction is not part of this build; "
-                                  "TensorNetwork contracts recognised chains with HIP kernels")
+        """Contracts self with other_node over the given labels (default: the labels that connect
+        them); labels both nodes carry and that are not contracted act as batch axes
+        (tensor/node.py:28-74).  The new node's axes are self's labels then other's, in order,
+        without the contracted ones (the reference orders them by set iteration, i.e. arbitrarily).
+        On the device the product is one row GEMM (no batch label) or one per-sample contraction
+        kernel (batch labels such as the sample axis)."""
+        if self is other_node:
+            return self
+        if contract_labels is None:
+            contract_labels = self.get_connecting_labels(other_node)
+        contract_labels = _as_list(contract_labels)
+        out_labels = [lab for lab in dict.fromkeys(self.dim_labels + other_node.dim_labels) if lab not in contract_labels]
+        tensor = _pair_contract(self.tensor, self.dim_labels, other_node.tensor, other_node.dim_labels, contract_labels,
+                                out_labels)
+        left = [lab for lab in self.left_labels + other_node.left_labels if lab not in contract_labels]
+        right = [lab for lab in self.right_labels + other_node.right_labels if lab not in contract_labels]
+        node = TensorNode(tensor, out_labels, l=left, r=right,
+                          name=f"<{self.name}-{','.join(contract_labels)}-{other_node.name}>")
+        node.contracted = self.contracted | other_node.contracted
+        if not self.contracted:
+            node.contracted.add(self)
+        if not other_node.contracted:
+            node.contracted.add(other_node)
+        for src in (self, other_node):      # edges to the outside survive, with the larger priority
+            for label, connected in src.connections.items():
+                if connected not in node.contracted:
+                    if label in node.connections:
+                        node.connection_priority[label] = max(node.connection_priority[label], src.connection_priority[label])
+                    else:
+                        node.connection_priority[label] = src.connection_priority[label]
+                    node.connections[label] = connected
+        return node
+
+    def contract_vertically(self, exclude=set()):
+        """Contracts every non-bond edge reachable from this node, edges of higher priority first
+        (tensor/node.py:149-167)."""
+        contracted = self
+        queue = [self]
+        while queue:
+            current = queue.pop(0)
+            for label, nxt in sorted(current.connections.items(), key=lambda it: current.connection_priority[it[0]],
+                                     reverse=True):
+                if nxt in exclude:
+                    continue
+                if label not in current.left_labels + current.right_labels:
+                    contracted = current.contract_with(nxt, nxt.get_connecting_labels(current, horizontal=False))
+                    queue.append(contracted)
+        return contracted
+
+    def get_vertical_nodes(self, exclude=set()):
+        """The nodes contract_vertically would visit, in its order (tensor/node.py:255-278)."""
+        order, visited, queue = [], set(), [self]
+        while queue:
+            current = queue.pop(0)
+            if current in visited:
+                continue
+            visited.add(current)
+            order.append(current)
+            for label, nxt in sorted(current.connections.items(), key=lambda it: current.connection_priority[it[0]],
+                                     reverse=True):
+                if nxt in exclude or nxt in visited:
+                    continue
+                if label not in current.left_labels + current.right_labels:
+                    queue.append(nxt)
+        return order
+
+    def get_transposed_node(self, exclude=set()):
+        """The same tensor under primed labels (tensor/node.py:169-171)."""
+        ren = lambda labs: [lab if lab in exclude else f'_{lab}' for lab in labs]   # noqa: E731
+        return TensorNode(self.tensor, ren(self.dim_labels), l=ren(self.left_labels), r=ren(self.right_labels),
+                          name='_' + self.name)
 
     # ---- tensor access ---------------------------------------------------
     @property

@@ -132,3 +132,59 @@ def test_feature_pair_classes_detection():
     sc = torch.stack([torch.cos(x), torch.sin(x)], dim=-1)
     assert pair_classes(sc) is None
     assert pair_classes(torch.rand(50, 12, dtype=torch.float64)) is None      # above the class limit: not attempted
+
+
+def check_pairwise_contraction(device):
+    """contract_with / contract_vertically against explicit einsums: a plain column (core with its
+    input), a sample-batched pair, a conv column (core - input - filter) and the bookkeeping of
+    labels, edges and the `contracted` set (tensor/node.py:28-74,149-167)."""
+    import torch
+    from tensornetworksfork_amd.tensor.layers import TensorConvolutionTrainLayer, TensorTrainLayer
+    from tensornetworksfork_amd.tensor.node import TensorNode
+    torch.set_default_dtype(torch.float64)
+    layer = TensorTrainLayer(3, 4, 5, output_shape=2, seed=1).to(device)
+    tn = layer.tensor_network
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(30, 5, generator=g).to(device)
+    tn.set_input(x)
+    A2, X2 = tn.main_nodes[1], tn.input_nodes[1]
+    col = A2.contract_with(X2)
+    plab = [lab for lab in A2.dim_labels if lab in X2.dim_labels]
+    assert len(plab) == 1 and plab[0] not in col.dim_labels and set(col.dim_labels) == (set(A2.dim_labels) | set(X2.dim_labels)) - set(plab)
+    ref = torch.einsum('lpr,sp->lrs', A2.tensor, X2.tensor)
+    got = col.tensor.permute([col.dim_labels.index(lab) for lab in [A2.dim_labels[0], A2.dim_labels[2], 's']])
+    assert torch.allclose(got, ref, rtol=1e-12, atol=1e-14)
+    assert col.contracted == {A2, X2} and col.left_labels == A2.left_labels and col.right_labels == A2.right_labels
+    assert set(col.connections.values()) == {tn.main_nodes[0], tn.main_nodes[2]}
+    assert A2.contract_vertically().tensor.shape == col.tensor.shape
+    # batch label: both operands carry 's'
+    E = TensorNode(torch.rand(30, 4, generator=g).to(device), ['s', A2.dim_labels[0]], name='E')
+    out = E.contract_with(col, [A2.dim_labels[0]])
+    assert out.dim_labels == ['s', A2.dim_labels[2]]
+    assert torch.allclose(out.tensor, torch.einsum('sl,lpr,sp->sr', E.tensor, A2.tensor, X2.tensor), rtol=1e-12, atol=1e-14)
+    # conv column: core - input - filter
+    torch.manual_seed(3)
+    conv = TensorConvolutionTrainLayer(2, 3, 6, 4, output_shape=2, convolution_bond=2).to(device).tensor_network
+    xc = torch.rand(20, 6, 4, generator=g).to(device)
+    conv.set_input(xc)
+    A1 = conv.main_nodes[0]
+    full = A1.contract_vertically()
+    C1 = [n for n in conv.train_nodes if n.name.startswith('C')][0]
+    X1 = conv.input_nodes[0]
+    ein = torch.einsum('abc,sbx,xd->sacd', A1.tensor.permute([A1.dim_labels.index(lab) for lab in A1.dim_labels]),
+                       X1.tensor, C1.tensor) if A1.tensor.ndim == 3 and C1.tensor.ndim == 2 else None
+    assert ein is not None and set(full.dim_labels) == {'s', A1.dim_labels[0], A1.dim_labels[2], C1.dim_labels[1]}
+    perm = [full.dim_labels.index(lab) for lab in ['s', A1.dim_labels[0], A1.dim_labels[2], C1.dim_labels[1]]]
+    assert torch.allclose(full.tensor.permute(perm), ein, rtol=1e-12, atol=1e-14)
+    assert [n.name for n in A1.get_vertical_nodes()] == [A1.name, X1.name, C1.name]
+    T = A1.get_transposed_node(exclude={'s'})
+    assert T.dim_labels == ['_' + lab for lab in A1.dim_labels] and T.tensor is A1.tensor
+
+
+def test_pairwise_contraction_host():
+    check_pairwise_contraction("cpu")
+
+
+@pytest.mark.gpu
+def test_pairwise_contraction_device():
+    check_pairwise_contraction("cuda:0")
