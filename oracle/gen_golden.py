@@ -382,9 +382,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests._net_cases import NET_CASES, net_builders as _net_builders  # noqa: E402
 
 
+# seeds follow this order; new cases go at the end so that the earlier fixtures regenerate unchanged
+_NET_ORDER = ["cpd_c1", "cpd_c2", "cumsum_c1", "sum_cpd_type1_c2", "sum_tt_type1_c1", "sum_ttlinear_type1_c1", "ttlinear_c2",
+              "graph_two_legs_c2", "graph_out_last_c3"]
+
+
 def gen_net(case, S=72, features=6):
     kind, C = NET_CASES[case]
-    seed = 200 + sorted(NET_CASES).index(case)
+    seed = 200 + _NET_ORDER.index(case)
     build = _net_builders(layers, network)[case]
     torch.manual_seed(seed)          # CumSumLayer does not seed itself
     layer = build()
@@ -487,3 +492,7 @@ if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_EXTRA", "1") == "1":
     gen_extra()
 if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_MANY_PATCHES", "1") == "1":
     gen_many_patches()
+if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_ONLY_NETS"):
+    # e.g. TTK_GOLDEN_BASE=0 TTK_GOLDEN_EXTRA=0 TTK_GOLDEN_MANY_PATCHES=0 TTK_GOLDEN_ONLY_NETS=graph_two_legs_c2,graph_out_last_c3
+    for case in os.environ["TTK_GOLDEN_ONLY_NETS"].split(","):
+        gen_net(case)

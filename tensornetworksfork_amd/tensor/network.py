@@ -40,7 +40,13 @@ class TensorNetwork:
         self._engine = self._make_engine()
 
     def _make_engine(self):
-        return ChainEngine(self)
+        """The chain engine for the recognised shapes; any other graph the reference's stack algorithm
+        can contract goes to the pairwise-contraction engine."""
+        eng = ChainEngine(self)
+        if eng.cols is None:
+            from .graph_engine import GraphEngine
+            return GraphEngine(self, chain_error=eng.error)
+        return eng
 
     def distribute(self, shard="auto"):
         """Shard the training samples of the sweep methods over the ranks of a

@@ -89,10 +89,16 @@ class TensorNode:
                 a.connections[label] = b
 
     def get_connecting_labels(self, other_node, horizontal=True):
+        """Labels of the edges between the two nodes; a node that is the result of contractions
+        stands for the nodes it was made of (tensor/node.py:103-113)."""
         def side(a, b):
             bonds = a.left_labels + a.right_labels
             return [lab for lab, n in a.connections.items() if n is b and (horizontal or lab not in bonds)]
-        return list(set(side(self, other_node) + side(other_node, self)))
+        found = set()
+        for a in (self.contracted or {self}):
+            for b in other_node.contracted | {other_node}:
+                found.update(side(a, b) + side(b, a))
+        return list(found)
 
     def is_horizontal_bond(self, label):
         return label in self.left_labels or label in self.right_labels
