@@ -175,6 +175,11 @@ int64_t ttk_chol_ws_bytes(int n);
 int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
                          const double* b, const double* w, void* chol_ws, void* stream);
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream);
+/* How ttk_chol_solve_f64 factorises (same call, same result up to rounding): 0 = one launch per
+ * panel and trailing update; 1 = the whole factorisation as one launch of tile tasks that wait on
+ * each other through progress words in the workspace; -1 (default) = 1 from 8 block columns on.
+ * Returns the previous mode; any other argument only queries. */
+int ttk_chol_mode(int mode);
 
 /* Reduced Householder QR of a row-major (m,n) matrix in one workgroup, LAPACK sign
  * conventions: A = Q R, Q (m,k), R (k,n), k = min(m,n).  Replaces torch.linalg.qr in

@@ -2584,6 +2584,521 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole factorisation as ONE launch: left-looking tile tasks pulled from a device-side
+// queue in an order in which every task depends only on earlier ones.
+//
+// Tiles are 64 x 64.  The task of tile (i, j), i > j, forms
+//     C = A_ij - sum_{k < j} L_ik L_jk^T            (MFMA, accumulators in registers)
+// as soon as the tiles L_ik, L_jk exist, then L_ij = C W_j^T with W_j = L_jj^-1 (one more MFMA
+// product straight from the accumulators) and publishes L_ij.  The task of the diagonal tile
+// (j, j) accumulates it the same way, factorises it with the 16-column in-register sub-panels of
+// chol_panel_kernel, inverts the factor blockwise (16 x 16 triangular inverses by substitution,
+// the other blocks by MFMA products) and publishes W_j.  Nothing waits for a kernel boundary: the chain of
+// diagonal tasks runs beside the accumulation of all tiles to its right, which is where the
+// flops are.  The right-hand side rides along as block row nb, as in the multi-launch path.
+//
+// Hand-off between workgroups (per-XCD L2s are not coherent, L1 is never refreshed): every
+// byte another workgroup will read is stored write-through (sc1) and every load of such bytes
+// is an sc1 load, so no cache ever holds an old copy; after its stores every wave waits for
+// vmcnt(0), the workgroup meets at a barrier, and one lane raises the row's progress word by an
+// sc1 store.  rowready[i] = number of finished tiles of block row i counted from the left
+// (k + 1 after tile (i, k); i + 1 once W_i is out).  Waiting lanes poll that word with relaxed
+// sc1 loads; every spin is bounded and gives up through the abort word, so every wave ends.
+// Task order = column by column, diagonal first: what a task waits for was always claimed
+// before it by a workgroup that is running, so the order cannot deadlock whatever the grid.
+// ---------------------------------------------------------------------------------------
+#define DAG_SLOT 32                    // 4-byte words per control slot (one 128-byte line each)
+#define DAG_CU_WORDS 4096              // per compute unit (8 dies x 256 ids): arrivals, role
+#ifdef TTK_DAG_TRACE
+// timestamps (100 MHz) of the diagonal chain, 16 per block column, behind the progress words
+#define DAG_TRACE(col, k) \
+  if (tid == 0) ((long long*)(ctl + (size_t)(nb + 2) * DAG_SLOT + DAG_CU_WORDS))[(col) * 16 + (k)] = wall_clock64();
+#else
+#define DAG_TRACE(col, k)
+#endif
+#define DAG_SPIN_LIMIT (1u << 21)     // polls before a waiting lane gives up (seconds)
+typedef unsigned int dag_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned dag_poll(unsigned* w) {
+  return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// two doubles by one 16-byte write-through store / sc1 load at byte offset `off` of the buffer
+__device__ __forceinline__ void dag_load2(__amdgpu_buffer_rsrc_t r, unsigned off, double& a, double& b) {
+  const dag_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+  a = __hiloint2double((int)v.y, (int)v.x);
+  b = __hiloint2double((int)v.w, (int)v.z);
+}
+__device__ __forceinline__ void dag_store2(__amdgpu_buffer_rsrc_t r, unsigned off, double a, double b) {
+  dag_u4 v;
+  v.x = (unsigned)__double2loint(a);
+  v.y = (unsigned)__double2hiint(a);
+  v.z = (unsigned)__double2loint(b);
+  v.w = (unsigned)__double2hiint(b);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+}
+
+// Accumulation of NQ tiles that share the column operand (block row j): acc[q][u][t] holds
+// C_q^T[c = 16u + 4t + kq][r = 16 wave + li].  Returns false when the launch was aborted.
+template <int NQ>
+__device__ __forceinline__ bool dag_accumulate(d4 (&acc)[NQ][4], double* stage, __amdgpu_buffer_rsrc_t rs, int ld, int j,
+                                               const int (&qrow)[NQ], unsigned* rowready, unsigned* ctl, unsigned* s_word,
+                                               int tid) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int srow = tid >> 2, sk = (tid & 3) * 4;
+  double (*Ps)[CHB + 1] = (double (*)[CHB + 1])stage;                       // [16][65], negated
+  double (*Qs)[NQ * CHB + 1] = (double (*)[NQ * CHB + 1])(stage + 16 * (CHB + 1));
+  const int nq = 4 * j;
+  unsigned avail = 0;
+  bool ok = true;
+  // progress of the rows this task reads: valid until `avail` tiles from the left
+  auto wait_avail = [&](unsigned kb) {
+    if (tid == 0) {
+      unsigned a = 0, spins = 0, dead = 0;
+      for (;;) {
+        a = dag_poll(rowready + (size_t)j * DAG_SLOT);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a = min(a, dag_poll(rowready + (size_t)qrow[q] * DAG_SLOT));
+        if (a > kb) break;
+        if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
+          dead = 1;
+          __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      s_word[2] = a;
+      s_word[3] = dead;
+    }
+    __syncthreads();
+    avail = s_word[2];
+    if (s_word[3]) ok = false;
+  };
+  const unsigned pbase = (unsigned)(((int64_t)(j * CHB + srow) * ld + sk) * 8);
+  unsigned qbase[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) qbase[q] = (unsigned)(((int64_t)(qrow[q] * CHB + srow) * ld + sk) * 8);
+  double pa[4], qa[NQ][4];
+  auto fetch = [&](int chunk) {
+    const unsigned o = (unsigned)chunk * 16u * 8u;
+    dag_load2(rs, pbase + o, pa[0], pa[1]);
+    dag_load2(rs, pbase + o + 16, pa[2], pa[3]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      dag_load2(rs, qbase[q] + o, qa[q][0], qa[q][1]);
+      dag_load2(rs, qbase[q] + o + 16, qa[q][2], qa[q][3]);
+    }
+  };
+  if (nq > 0) {
+    wait_avail(0);
+    if (!ok) return false;
+    fetch(0);
+  }
+  for (int c = 0; c < nq; ++c) {
+    if (c) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Ps[sk + e][srow] = -pa[e];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) Qs[sk + e][q * CHB + srow] = qa[q][e];
+    }
+    __syncthreads();
+    const bool more = c + 1 < nq;
+    const bool known = more && ((((c + 1) & 3) != 0) || (unsigned)((c + 1) >> 2) < avail);
+    if (known) fetch(c + 1);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+      double af[4], bf[NQ];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) af[u] = Ps[k0 + kq][16 * u + li];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bf[q] = Qs[k0 + kq][q * CHB + 16 * wave + li];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[q][u] = MFMA_F64(af[u], bf[q], acc[q][u]);
+    }
+    if (more && !known) {
+      wait_avail((unsigned)((c + 1) >> 2));
+      if (!ok) return false;
+      fetch(c + 1);
+    }
+  }
+  __syncthreads();   // the staging area is free again
+  return true;
+}
+
+// out^T = W C^T for the tile whose C^T sits in `c` (accumulator layout of dag_accumulate), W row-major in
+// R; the result goes through R to block (irow, j) of the matrix by coalesced write-through stores.
+__device__ __forceinline__ void dag_finish_tile(const d4 (&c)[4], chol_lds_t R, __amdgpu_buffer_rsrc_t rs, int ld, int irow,
+                                                int j, int tid) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  d4 o[4];
+#pragma unroll
+  for (int up = 0; up < 4; ++up) {
+    o[up] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u <= up; ++u)   // W is lower triangular: blocks right of the diagonal are zero
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[up] = MFMA_F64(R[16 * up + li][16 * u + 4 * t + kq], c[u][t], o[up]);
+  }
+  __syncthreads();   // every wave has read W
+#pragma unroll
+  for (int up = 0; up < 4; ++up)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R[16 * wave + li][16 * up + 4 * t + kq] = o[up][t];
+  __syncthreads();
+  const unsigned base = (unsigned)(((int64_t)irow * CHB * ld + (int64_t)j * CHB) * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int id = tid + 256 * e;
+    const int r = id >> 5, pc = (id & 31) * 2;
+    dag_store2(rs, base + (unsigned)(((int64_t)r * ld + pc) * 8), R[r][pc], R[r][pc + 1]);
+  }
+}
+
+// LDS of the single-launch factorisation (file scope: the non-inlined pieces of the diagonal task use it too).
+__shared__ double dagR[CHB][CHB + 1];   // in turn: staging of the accumulation, diagonal tile, W, result tile
+__shared__ double dag_rsd[CHB];
+__shared__ double dag_piv[16];
+__shared__ double dag_colb[2][CHB];
+__shared__ unsigned dag_word[4];
+__shared__ unsigned dag_role;
+
+// Entry (i, k) of the inverse of the 16 x 16 diagonal block `a` of the factor in dagR: strictly lower
+// entries are kept transposed above the diagonal of that block, the diagonal is dag_rsd.
+__device__ __forceinline__ double dag_dinv(int a, int i, int k) {
+  const double lo = dagR[16 * a + min(i, k)][16 * a + max(i, k)];
+  return i > k ? lo : (i == k ? dag_rsd[16 * a + i] : 0.0);
+}
+
+// One wave: right-looking factorisation of the 16-column sub-panel at c0 of the tile in dagR, one matrix row
+// per lane (the F step of chol_panel_kernel).  Returns 0, or 1 + the column of the first non-positive pivot.
+__device__ __forceinline__ int dag_f16(int c0) {
+  const int lane = threadIdx.x & 63;
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = dagR[lane][c0 + c];
+  double d = readlane_f64(a[0], c0);
+  double rc = rcp_f64(d);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (lane == 0) dag_piv[c] = d;
+    dag_colb[c & 1][lane] = a[c];
+    asm volatile("" ::: "memory");
+    const double t = -a[c] * rc;
+    if (c + 1 < 16) {
+      a[c + 1] = fma(t, readlane_f64(a[c], c0 + c + 1), a[c + 1]);
+      d = readlane_f64(a[c + 1], c0 + c + 1);
+      rc = rcp_f64(d);
+    }
+#pragma unroll
+    for (int cc = c + 2; cc < 16; ++cc) a[cc] = fma(t, dag_colb[c & 1][c0 + cc], a[cc]);
+  }
+  const double dv = dag_piv[lane & 15];
+  double rsv, sqv;
+  rsqrt_sqrt(dv, rsv, sqv);
+  const unsigned long long badmask = __ballot(!(dv > 0.0)) & 0xffffull;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] *= readlane_f64(rsv, c);
+  if (lane < 16) dag_rsd[c0 + lane] = rsv;
+  if (lane >= c0) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dagR[lane][c0 + c] = a[c];
+  }
+  return badmask ? c0 + __builtin_ctzll(badmask) + 1 : 0;
+}
+
+// One wave: inverse of the 16 x 16 lower-triangular block at s0 by forward substitution, one column per lane;
+// row r of the block is fetched while row r-1 is summed (the empty asm keeps the compiler from issuing all
+// 120 loads at once).  The strictly lower part of the inverse goes, transposed, above the block's diagonal.
+__device__ __forceinline__ void dag_dinv16(int s0) {
+  const int lane = threadIdx.x & 63, cc = lane & 15;
+  double z[16], cur[16], nxt[16];
+  z[0] = cc == 0 ? dag_rsd[s0] : 0.0;
+  cur[0] = dagR[s0 + 1][s0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) {
+    if (r + 1 < 16) {
+#pragma unroll
+      for (int k = 0; k <= r; ++k) nxt[k] = dagR[s0 + r + 1][s0 + k];
+    }
+    double sa = 0.0, sb = 0.0;   // two chains: half the dependent latency
+#pragma unroll
+    for (int k = 0; k < r; ++k) {
+      if (k & 1)
+        sb = fma(cur[k], z[k], sb);
+      else
+        sa = fma(cur[k], z[k], sa);
+    }
+    const double rr_ = dag_rsd[s0 + r];
+    z[r] = (r == cc) ? rr_ : (r > cc ? -(sa + sb) * rr_ : 0.0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k <= r; ++k) cur[k] = nxt[k];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r)
+      if (r > cc) dagR[s0 + cc][s0 + r] = z[r];
+  }
+}
+
+// All four waves: W = L^-1 of the factorised tile in dagR, by block distance from the diagonal:
+// W_ab = -Dinv_a * sum_{m=b}^{a-1} L_am W_mb, W_bb = Dinv_b.  Blocks of W (and the sums before them) live
+// untransposed in the upper block (b, a); at the end W stands row-major in dagR in place of the factor.
+__device__ __forceinline__ void dag_invert() {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  chol_lds_t R = dagR;
+#pragma unroll 1
+  for (int dist = 1; dist < 4; ++dist) {
+    if (wave < 4 - dist) {
+      const int b = wave, a = wave + dist;
+      d4 q = d4{0.0, 0.0, 0.0, 0.0};
+      for (int m = b; m < a; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double x = R[16 * a + li][16 * m + 4 * s + kq];                 // L_am[li][k]
+          const double y = m == b ? dag_dinv(b, 4 * s + kq, li)                  // W_mb[k][li]
+                                  : R[16 * b + 4 * s + kq][16 * m + li];
+          q = MFMA_F64(x, y, q);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = q[t];
+    }
+    __syncthreads();
+    if (wave < 4 - dist) {
+      const int b = wave, a = wave + dist;
+      d4 w = d4{0.0, 0.0, 0.0, 0.0};
+      double y[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y[s] = R[16 * b + 4 * s + kq][16 * a + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w = MFMA_F64(-dag_dinv(a, li, 4 * s + kq), y[s], w);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = w[t];
+    }
+    __syncthreads();
+  }
+  double wv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = tid + 256 * e;
+    const int r = idx >> 6, c = idx & 63, a = r >> 4, b = c >> 4;
+    wv[e] = a > b ? R[16 * b + (r & 15)][16 * a + (c & 15)] : (a == b ? dag_dinv(a, r & 15, c & 15) : 0.0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = tid + 256 * e;
+    R[idx >> 6][idx & 63] = wv[e];
+  }
+  __syncthreads();
+}
+
+// Everything of a diagonal task behind the accumulation, as ONE non-inlined function: factorisation of the
+// tile in dagR by 16-column sub-panels (see chol_panel_kernel; wave 1 inverts the diagonal 16 x 16 block of the
+// sub-panel before), then the inverse of the factor.  A function of its own has its own register allocation:
+// the long unrolled chains here do not crowd the accumulation loops of the kernel, and the callee-saved
+// registers are saved once per task.  Returns 0, or 1 + the column of the first non-positive pivot.
+__device__ __attribute__((noinline)) int dag_diag_tail(int j, int nb, unsigned* ctl) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  chol_lds_t R = dagR;
+  (void)j; (void)nb; (void)ctl; (void)lane;
+    int badcol = 0;
+#pragma unroll 1
+    for (int ph = 0; ph <= 4; ++ph) {
+      const int c0 = ph * 16;
+      if (wave == 0) {
+        if (ph < 4) {
+          const int bc = dag_f16(c0);
+          if (bc && !badcol) badcol = bc;
+        }
+      } else if (wave == 1) {
+        if (ph >= 1) dag_dinv16(c0 - 16);
+      } else {
+        int n = wave - 2;
+        if (ph >= 1) {
+          for (int tj = ph + 1; tj < 4; ++tj)
+            for (int ti = tj; ti < 4; ++ti, ++n)
+              if (!(n & 1)) chol_tile_update(R, R, R, ti, tj, c0 - 16, li, kq);
+        }
+      }
+      __syncthreads();
+      if (ph == 0) { DAG_TRACE(j, 12) }
+      if (ph == 1) { DAG_TRACE(j, 14) }
+      if (ph == 2) { DAG_TRACE(j, 15) }
+      if (ph == 4) break;
+      {
+        int n = wave;
+        if (ph < 3)
+          for (int ti = ph + 1; ti < 4; ++ti, ++n)
+            if (!(n & 3)) chol_tile_update(R, R, R, ti, ph + 1, c0, li, kq);
+      }
+      __syncthreads();
+      if (ph == 0) { DAG_TRACE(j, 13) }
+    }
+    DAG_TRACE(j, 3)
+    dag_invert();
+  return badcol;
+}
+
+__global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ aug, int ld, int nb, unsigned aug_bytes,
+                                                          double* __restrict__ Winv, int* __restrict__ info,
+                                                          unsigned* __restrict__ ctl, int nchain) {
+  chol_lds_t R = dagR;
+  unsigned* s_word = dag_word;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)aug, 0, (int)aug_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Winv, 0, nb * CHB * CHB * (int)sizeof(double), 0x00020000);
+  unsigned* rowready = ctl + DAG_SLOT;
+  const int ntasks = nb * (nb + 1) / 2;   // tiles (i, j), i = j+1 .. nb, column by column
+  // Roles.  The factorisation of a diagonal tile is one long chain of dependent fp64 operations; beside
+  // waves that keep the matrix pipe busy it runs three times slower.  So the first workgroup to arrive on
+  // each of the first `nchain` compute units takes diagonal tasks only and every other workgroup that lands
+  // on such a unit leaves at once; all remaining workgroups take the off-diagonal tiles.
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));    // HW_ID[15:8]: engine, array, unit
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));             // XCC_ID[3:0]
+    unsigned* cu = ctl + (size_t)(nb + 2) * DAG_SLOT + 2 * (((xcc & 7u) << 8) | (hw & 255u));
+    unsigned role = 0;
+    if (atomicAdd(cu, 1u) == 0) {
+      role = atomicAdd(ctl + 3, 1u) < (unsigned)nchain ? 2u : 1u;
+      __hip_atomic_store(cu + 1, role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (unsigned spins = 0; (role = dag_poll(cu + 1)) == 0 && spins < DAG_SPIN_LIMIT; ++spins) __builtin_amdgcn_s_sleep(2);
+      if (role == 2) role = 3;
+    }
+    dag_role = role;
+  }
+  __syncthreads();
+  const unsigned role = dag_role;
+  if (role != 1 && role != 2) return;
+  for (;;) {
+    // The thread index is made opaque once per task: everything derived from it (LDS and global
+    // offsets of the unrolled code below) is then computed where it is used instead of being kept
+    // in registers across the whole task loop.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    if (tid == 0) {
+      s_word[0] = atomicAdd(role == 2 ? ctl + 2 : ctl, 1u);
+      s_word[1] = dag_poll(ctl + 1);
+    }
+    __syncthreads();
+    const int task = (int)s_word[0];
+    const bool stop = s_word[1] != 0;
+    __syncthreads();
+    const bool diag = role == 2;
+    if (task >= (diag ? nb : ntasks) || stop) return;
+    int j = diag ? task : 0, rem = diag ? 0 : task;
+    while (!diag && rem >= nb - j) {
+      rem -= nb - j;
+      ++j;
+    }
+    const int r_own = 16 * wave + li;   // row of the tile this lane's accumulators belong to
+    if (!diag) {
+      // ---------------------------------------------------------------- tile (i, j), i > j
+      const int i = j + 1 + rem;
+      d4 acc[1][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[0][u][t] = aug[(int64_t)(i * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
+      const int qrow[1] = {i};
+      if (!dag_accumulate<1>(acc, &dagR[0][0], rs, ld, j, qrow, rowready, ctl, s_word, tid)) return;
+      // W_j
+      if (tid == 0) {
+        unsigned spins = 0, dead = 0;
+        while (dag_poll(rowready + (size_t)j * DAG_SLOT) < (unsigned)(j + 1)) {
+          if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
+            dead = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        s_word[3] = dead;
+      }
+      __syncthreads();
+      if (s_word[3]) {
+        if (tid == 0) __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;   // uniform: every thread read the same word behind the barrier
+      }
+      if (i == j + 1) { DAG_TRACE(j, 8) }
+      {
+        double wv[16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int id = tid + 256 * e;
+          dag_load2(rw, (unsigned)((j * CHB * CHB + id * 2) * 8), wv[2 * e], wv[2 * e + 1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int id = tid + 256 * e;
+          const int r = id >> 5, pc = (id & 31) * 2;
+          R[r][pc] = wv[2 * e];
+          R[r][pc + 1] = wv[2 * e + 1];
+        }
+      }
+      __syncthreads();
+      if (i == j + 1) { DAG_TRACE(j, 9) }
+      dag_finish_tile(acc[0], R, rs, ld, i, j, tid);
+      if (i == j + 1) { DAG_TRACE(j, 10) }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (i == j + 1) { DAG_TRACE(j, 11) }
+      if (tid == 0)
+        __hip_atomic_store(rowready + (size_t)i * DAG_SLOT, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // ------------------------------------------------------------------ diagonal task of column j
+    d4 acc[1][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 16 * u + 4 * t + kq;
+        const double v = aug[(int64_t)(j * CHB + r_own) * ld + j * CHB + c];
+        acc[0][u][t] = c <= r_own ? v : 0.0;   // only the lower triangle of A_jj is stored
+      }
+    const int qrow[1] = {j};
+    if (!dag_accumulate<1>(acc, &dagR[0][0], rs, ld, j, qrow, rowready, ctl, s_word, tid)) return;
+    DAG_TRACE(j, 1)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 16 * u + 4 * t + kq;
+        R[r_own][c] = c <= r_own ? acc[0][u][t] : 0.0;
+      }
+    __syncthreads();
+    DAG_TRACE(j, 2)
+    {
+      const int badcol = dag_diag_tail(j, nb, ctl);
+      if (wave == 0 && badcol && lane == 0) atomicCAS(info, 0, j * CHB + badcol);
+    }
+    DAG_TRACE(j, 4)
+    {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int id = tid + 256 * e;
+        const int r = id >> 5, pc = (id & 31) * 2;
+        dag_store2(rw, (unsigned)((j * CHB * CHB + id * 2) * 8), R[r][pc], R[r][pc + 1]);
+      }
+    }
+    DAG_TRACE(j, 5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DAG_TRACE(j, 6)
+    if (tid == 0)
+      __hip_atomic_store(rowready + (size_t)j * DAG_SLOT, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Gram expansion straight into the Cholesky storage: lower triangle of A/scale + ridge*I,
 // identity on the padded diagonal, zero elsewhere in the padded rows.
 __global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __restrict__ G, int rl, int p, int rr,
@@ -3104,10 +3619,24 @@ int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, con
   return ttk_launch_status();
 }
 
+// workspace: [ aug ((nb+1)*64 x nb*64) | inverses of the diagonal blocks (nb x 64 x 64) | control block of the
+// single-launch factorisation: task counters + abort word in slot 0, one progress word per block row, the
+// table of compute units ]
+static inline int64_t chol_ctl_offset(int64_t nb) {
+  return round_up64(((nb + 1) * CHB * nb * CHB + nb * CHB * CHB) * (int64_t)sizeof(double), 256);
+}
+static inline int64_t chol_ctl_bytes(int64_t nb) {
+  int64_t bytes = ((nb + 2) * DAG_SLOT + DAG_CU_WORDS) * (int64_t)sizeof(unsigned);
+#ifdef TTK_DAG_TRACE
+  bytes += nb * 16 * (int64_t)sizeof(long long);
+#endif
+  return bytes;
+}
+
 int64_t ttk_chol_ws_bytes(int n) {
   if (n < 1) return TTK_EINVAL;
   const int64_t nb = (n + CHB - 1) / CHB;
-  return ((nb + 1) * CHB * nb * CHB + nb * CHB * CHB) * (int64_t)sizeof(double) + 256;
+  return chol_ctl_offset(nb) + chol_ctl_bytes(nb) + 256;
 }
 
 int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
@@ -3165,6 +3694,46 @@ int ttk_debug_env_reg(int on) { g_env_reg = on; return 0; }
 int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
 #endif
 
+// 0: one launch per panel / trailing update; 1: the single-launch factorisation; -1: single launch from
+// CHOL_DAG_MIN_NB block columns on (below that the few launches of the first form are as fast)
+#define CHOL_DAG_MIN_NB 8
+static int g_chol_mode = 0;    // the single-launch form is opt-in until it is the faster one
+static int g_dag_chain = 0;   // compute units kept for the diagonal chain; 0: chosen from the order
+int ttk_chol_mode(int mode) {
+  if (mode >= 100) {   // tuning: 100 + units
+    g_dag_chain = mode - 100;
+    return g_chol_mode;
+  }
+  const int old = g_chol_mode;
+  if (mode >= -1 && mode <= 1) g_chol_mode = mode;
+  return old;
+}
+
+// workgroups of the single-launch factorisation that fit the device at once (more would only queue)
+static int chol_dag_slots() {
+  static std::mutex mu;
+  static int slots[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (slots[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    slots[dev] = per_cu * cus;
+  }
+  return slots[dev];
+}
+
+static int chol_back_substitute(hipStream_t st, double* aug, int ld, int nb, const double* invL, double* x, int n) {
+  for (int jhi = nb - 1; jhi >= 0; jhi -= BKG) {
+    const int jlo = jhi - BKG + 1 > 0 ? jhi - BKG + 1 : 0;
+    hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(jlo > 0 ? jlo : 1)), dim3(256), 0, st, aug, ld, nb, jlo, jhi, invL,
+                       x, n);
+  }
+  return ttk_launch_status();
+}
+
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
   if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -3175,6 +3744,20 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   double* aug = (double*)chol_ws;
   double* invL = aug + (int64_t)nbr * CHB * ld;
   if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return TTK_ELAUNCH;
+  const int64_t aug_bytes = (int64_t)nbr * CHB * ld * (int64_t)sizeof(double);
+  const bool dag = (g_chol_mode == 1 || (g_chol_mode < 0 && nb >= CHOL_DAG_MIN_NB)) && aug_bytes < (int64_t(1) << 32);
+  if (dag) {
+    // every word the kernel polls or counts starts at zero
+    unsigned* ctl = (unsigned*)((char*)chol_ws + chol_ctl_offset(nb));
+    if (hipMemsetAsync(ctl, 0, (size_t)chol_ctl_bytes(nb), st) != hipSuccess) return TTK_ELAUNCH;
+    // every slot of the device gets a workgroup, so that each compute unit sees its first arrival at once
+    const int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(16, nb / 4));
+    hipLaunchKernelGGL(chol_dag_kernel, dim3((unsigned)chol_dag_slots()), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes,
+                       invL, info, ctl, nchain);
+    int rc = ttk_launch_status();
+    if (rc != TTK_OK) return rc;
+    return chol_back_substitute(st, aug, ld, nb, invL, x, n);   // invL already holds the inverses
+  }
   // One stream.  (A look-ahead that factorises the next pair of panels on a second,
   // high-priority stream beside the trailing update was measured and gained nothing: the
   // panel workgroups queue behind resident trailing-update workgroups for CU space.)
@@ -3204,12 +3787,7 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)nb), dim3(256), 0, st, invL);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
-  for (int jhi = nb - 1; jhi >= 0; jhi -= BKG) {
-    const int jlo = jhi - BKG + 1 > 0 ? jhi - BKG + 1 : 0;
-    hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(jlo > 0 ? jlo : 1)), dim3(256), 0, st, aug, ld, nb, jlo, jhi, invL,
-                       x, n);
-  }
-  return ttk_launch_status();
+  return chol_back_substitute(st, aug, ld, nb, invL, x, n);
 }
 
 int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {

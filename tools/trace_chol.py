@@ -1,0 +1,34 @@
+"""Timeline of the diagonal chain of the single-launch Cholesky (library built with -DTTK_DAG_TRACE,
+path in TTK_LIB_PATH).  usage: TTK_LIB_PATH=tools/libttk_trace.so python tools/trace_chol.py [n]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from tensornetworksfork_amd import ops  # noqa: E402
+from tools.time_chol import problem  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
+dev = torch.device("cuda:0")
+A, b = problem(n, dev)
+ops.chol_mode(1)
+for _ in range(3):
+    x, info = ops.chol_solve_dense(A, b)
+torch.cuda.synchronize()
+nb = (n + 63) // 64
+cw = ops._chol_ws[(A.device, n)]
+off = ((nb + 1) * 64 * nb * 64 + nb * 64 * 64) * 8
+off = (off + 255) // 256 * 256 + (nb + 2) * 128 + 4096 * 4
+tr = cw.view(torch.int64)[off // 8: off // 8 + nb * 16].reshape(nb, 16).cpu().double() / 100.0   # microseconds
+names = ["acc->lds", "F loop", "W stages", "assemble+store", "drain", "flag->OFF sees W", "W load", "finish", "drain", "flag->next acc done"]
+pairs = [(1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 8), (8, 9), (9, 10), (10, 11)]
+lo, hi = min(8, nb - 2), nb - 2
+print(f"n={n} nb={nb} total {tr[nb - 1, 6] - tr[0, 1]:.1f} us; per column {(tr[hi, 1] - tr[lo, 1]) / (hi - lo):.2f} us (columns {lo}..{hi})")
+for name, (a, c) in zip(names, pairs):
+    d = tr[lo:hi, c] - tr[lo:hi, a]
+    print(f"  {name:22s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f}")
+for name, (a, c) in [("  phase A0 (F0 alone)", (2, 12)), ("  phase B0", (12, 13)), ("  phase A1", (13, 14)), ("  B1+A2", (14, 15))]:
+    d = tr[lo:hi, c] - tr[lo:hi, a]
+    print(f"  {name:22s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f}")
+d = tr[lo + 1:hi + 1, 1] - tr[lo:hi, 11]
+print(f"  {names[-1]:22s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f}")
