@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ttk.h"
 
@@ -2585,18 +2586,28 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
 }
 
 // ---------------------------------------------------------------------------------------
-// The whole factorisation as ONE launch: left-looking tile tasks pulled from a device-side
-// queue in an order in which every task depends only on earlier ones.
+// The whole factorisation as ONE launch: left-looking tile tasks pulled from device-side
+// queues in an order in which every task depends only on earlier ones.
 //
-// Tiles are 64 x 64.  The task of tile (i, j), i > j, forms
+// Tiles are 64 x 64.  A worker task owns tiles (i, j) and (i+1, j) below the sub-diagonal
+// (i = j+2, j+4, ...): it forms
 //     C = A_ij - sum_{k < j} L_ik L_jk^T            (MFMA, accumulators in registers)
 // as soon as the tiles L_ik, L_jk exist, then L_ij = C W_j^T with W_j = L_jj^-1 (one more MFMA
-// product straight from the accumulators) and publishes L_ij.  The task of the diagonal tile
-// (j, j) accumulates it the same way, factorises it with the 16-column in-register sub-panels of
-// chol_panel_kernel, inverts the factor blockwise (16 x 16 triangular inverses by substitution,
-// the other blocks by MFMA products) and publishes W_j.  Nothing waits for a kernel boundary: the chain of
-// diagonal tasks runs beside the accumulation of all tiles to its right, which is where the
-// flops are.  The right-hand side rides along as block row nb, as in the multi-launch path.
+// product straight from the accumulators) and publishes L_ij.  The diagonal task of column j
+// owns tiles (j, j) and (j+1, j): it accumulates both, factorises the diagonal tile with the
+// 16-column in-register sub-panels of chol_panel_kernel, inverts the factor blockwise (16 x 16
+// triangular inverses by substitution, the other blocks by MFMA products), publishes W_j,
+// finishes its second tile and publishes L_{j+1,j}.  Nothing waits for a kernel boundary: the
+// chain of diagonal tasks runs beside the accumulation of all tiles to its right, which is where
+// the flops are.  The right-hand side rides along as block row nb, as in the multi-launch path.
+//
+// Roles.  The factorisation of a diagonal tile is one long chain of dependent fp64 operations;
+// beside waves that keep the matrix pipe busy it runs three times slower.  So the first
+// workgroup to arrive on each of the first `nchain` compute units takes diagonal tasks only and
+// every other workgroup that lands on such a unit leaves at once; all remaining workgroups are
+// workers.  Both queues are served in column order and each task waits only for tasks that come
+// earlier in the merged order (diagonal of column j, then the tiles of column j), so whatever
+// has been claimed can always finish: no deadlock, whatever the grid and the placement.
 //
 // Hand-off between workgroups (per-XCD L2s are not coherent, L1 is never refreshed): every
 // byte another workgroup will read is stored write-through (sc1) and every load of such bytes
@@ -2605,13 +2616,11 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
 // sc1 store.  rowready[i] = number of finished tiles of block row i counted from the left
 // (k + 1 after tile (i, k); i + 1 once W_i is out).  Waiting lanes poll that word with relaxed
 // sc1 loads; every spin is bounded and gives up through the abort word, so every wave ends.
-// Task order = column by column, diagonal first: what a task waits for was always claimed
-// before it by a workgroup that is running, so the order cannot deadlock whatever the grid.
 // ---------------------------------------------------------------------------------------
 #define DAG_SLOT 32                    // 4-byte words per control slot (one 128-byte line each)
 #define DAG_CU_WORDS 4096              // per compute unit (8 dies x 256 ids): arrivals, role
 #ifdef TTK_DAG_TRACE
-// timestamps (100 MHz) of the diagonal chain, 16 per block column, behind the progress words
+// timestamps (100 MHz) of the diagonal chain, 16 per block column, behind the table of compute units
 #define DAG_TRACE(col, k) \
   if (tid == 0) ((long long*)(ctl + (size_t)(nb + 2) * DAG_SLOT + DAG_CU_WORDS))[(col) * 16 + (k)] = wall_clock64();
 #else
@@ -2620,11 +2629,23 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
 #define DAG_SPIN_LIMIT (1u << 21)     // polls before a waiting lane gives up (seconds)
 typedef unsigned int dag_u4 __attribute__((ext_vector_type(4)));
 
+__shared__ double dagR[CHB][CHB + 1];   // in turn: diagonal tile, W
+__shared__ double dagS[CHB][CHB + 1];   // in turn: staging of the accumulation, result tile on its way out
+__shared__ double dagDv[4][16][17];      // inverses of the four 16 x 16 diagonal blocks of the factor
+__shared__ double dag_rsd[CHB];
+__shared__ double dag_piv[16];
+__shared__ double dag_colb[2][CHB];
+__shared__ unsigned dag_word[4];
+__shared__ unsigned dag_role;
+
 __device__ __forceinline__ unsigned dag_poll(unsigned* w) {
   return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void dag_post(unsigned* w, unsigned v) {
+  __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// two doubles by one 16-byte write-through store / sc1 load at byte offset `off` of the buffer
+// two doubles by one 16-byte sc1 load / write-through store at byte offset `off` of the buffer
 __device__ __forceinline__ void dag_load2(__amdgpu_buffer_rsrc_t r, unsigned off, double& a, double& b) {
   const dag_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
   a = __hiloint2double((int)v.y, (int)v.x);
@@ -2639,100 +2660,180 @@ __device__ __forceinline__ void dag_store2(__amdgpu_buffer_rsrc_t r, unsigned of
   __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
 }
 
-// Accumulation of NQ tiles that share the column operand (block row j): acc[q][u][t] holds
-// C_q^T[c = 16u + 4t + kq][r = 16 wave + li].  Returns false when the launch was aborted.
+// Waits until block rows `ra`, `rb` and `rc` have at least `need` finished tiles.  One lane polls, the workgroup
+// meets at a barrier.  Returns the progress seen (>= need), or 0 when the launch was aborted (or this wait ran
+// out of patience and aborted it).  need >= 1.
+__device__ __forceinline__ unsigned dag_wait(unsigned* rowready, unsigned* ctl, int ra, int rb, int rc, unsigned need,
+                                             int tid) {
+  if (tid == 0) {
+    unsigned a = 0, spins = 0;
+    for (;;) {
+      a = min(dag_poll(rowready + (size_t)ra * DAG_SLOT), dag_poll(rowready + (size_t)rb * DAG_SLOT));
+      if (rc != rb) a = min(a, dag_poll(rowready + (size_t)rc * DAG_SLOT));
+      if (a >= need) break;
+      if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
+        dag_post(ctl + 1, 1u);
+        a = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    dag_word[2] = a;
+  }
+  __syncthreads();
+  const unsigned seen = dag_word[2];
+  __syncthreads();
+  return seen;
+}
+
+// Accumulation over the block columns [kb0, kb1) for NQ tiles that share the column operand (block row j):
+//   acc[q][u][t] -= sum_k L_j[c = 16u + 4t + kq][k] * L_qrow[q][r = 16 wave + li][k]      (C^T, see dag_finish_tile)
+// Operands travel global -> registers -> LDS (k-major chunks of 16) -> MFMA fragments.  The registers hold one
+// whole block column (4 chunks); while a block is multiplied the next one is already on its way, if it exists
+// (else the task waits at the frontier and then fetches the four chunks together).  Returns false on abort.
 template <int NQ>
-__device__ __forceinline__ bool dag_accumulate(d4 (&acc)[NQ][4], double* stage, __amdgpu_buffer_rsrc_t rs, int ld, int j,
-                                               const int (&qrow)[NQ], unsigned* rowready, unsigned* ctl, unsigned* s_word,
-                                               int tid) {
+__device__ __forceinline__ bool dag_accumulate(d4 (&acc)[NQ][4], __amdgpu_buffer_rsrc_t rs, int ld, int j,
+                                               const int (&qrow)[NQ], int kb0, int kb1, unsigned* rowready,
+                                               unsigned* ctl, int tid) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   const int srow = tid >> 2, sk = (tid & 3) * 4;
-  double (*Ps)[CHB + 1] = (double (*)[CHB + 1])stage;                       // [16][65], negated
-  double (*Qs)[NQ * CHB + 1] = (double (*)[NQ * CHB + 1])(stage + 16 * (CHB + 1));
-  const int nq = 4 * j;
-  unsigned avail = 0;
-  bool ok = true;
-  // progress of the rows this task reads: valid until `avail` tiles from the left
-  auto wait_avail = [&](unsigned kb) {
-    if (tid == 0) {
-      unsigned a = 0, spins = 0, dead = 0;
-      for (;;) {
-        a = dag_poll(rowready + (size_t)j * DAG_SLOT);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a = min(a, dag_poll(rowready + (size_t)qrow[q] * DAG_SLOT));
-        if (a > kb) break;
-        if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
-          dead = 1;
-          __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      s_word[2] = a;
-      s_word[3] = dead;
-    }
-    __syncthreads();
-    avail = s_word[2];
-    if (s_word[3]) ok = false;
-  };
+  double (*Ps)[CHB + 1] = (double (*)[CHB + 1]) & dagS[0][0];                       // [16][65], negated
+  double (*Qs)[NQ * CHB + 1] = (double (*)[NQ * CHB + 1])(&dagS[0][0] + 16 * (CHB + 1));
+  if (kb0 >= kb1) return true;
   const unsigned pbase = (unsigned)(((int64_t)(j * CHB + srow) * ld + sk) * 8);
   unsigned qbase[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) qbase[q] = (unsigned)(((int64_t)(qrow[q] * CHB + srow) * ld + sk) * 8);
-  double pa[4], qa[NQ][4];
-  auto fetch = [&](int chunk) {
-    const unsigned o = (unsigned)chunk * 16u * 8u;
-    dag_load2(rs, pbase + o, pa[0], pa[1]);
-    dag_load2(rs, pbase + o + 16, pa[2], pa[3]);
+  double pa[4][4], qa[4][NQ][4];
+  auto fetch = [&](int kb) {   // the whole block column kb: 4 chunks of 16
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      dag_load2(rs, qbase[q] + o, qa[q][0], qa[q][1]);
-      dag_load2(rs, qbase[q] + o + 16, qa[q][2], qa[q][3]);
+    for (int c = 0; c < 4; ++c) {
+      const unsigned o = (unsigned)(kb * 4 + c) * 128u;
+      dag_load2(rs, pbase + o, pa[c][0], pa[c][1]);
+      dag_load2(rs, pbase + o + 16, pa[c][2], pa[c][3]);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        dag_load2(rs, qbase[q] + o, qa[c][q][0], qa[c][q][1]);
+        dag_load2(rs, qbase[q] + o + 16, qa[c][q][2], qa[c][q][3]);
+      }
     }
   };
-  if (nq > 0) {
-    wait_avail(0);
-    if (!ok) return false;
-    fetch(0);
-  }
-  for (int c = 0; c < nq; ++c) {
-    if (c) __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      Ps[sk + e][srow] = -pa[e];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) Qs[sk + e][q * CHB + srow] = qa[q][e];
+  unsigned avail = 0;
+  bool have = false;
+  bool first = true;
+  for (int kb = kb0; kb < kb1; ++kb) {
+    if (!have) {
+      if ((unsigned)kb >= avail) {
+        avail = dag_wait(rowready, ctl, j, qrow[0], qrow[NQ - 1], (unsigned)kb + 1u, tid);
+        if (!avail) return false;
+      }
+      fetch(kb);
     }
-    __syncthreads();
-    const bool more = c + 1 < nq;
-    const bool known = more && ((((c + 1) & 3) != 0) || (unsigned)((c + 1) >> 2) < avail);
-    if (known) fetch(c + 1);
+    const bool pre = kb + 1 < kb1 && (unsigned)(kb + 1) < avail;
+    // Two copies of the block body, with and without the prefetch: inside each the loads are unconditional,
+    // so the compiler can count how many younger loads may still be in flight when a chunk's registers are
+    // needed, instead of waiting for all of them.
+    auto body = [&](auto prefetch) {
 #pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 4) {
-      double af[4], bf[NQ];
+      for (int c = 0; c < 4; ++c) {
+        if (!first) __syncthreads();   // the fragments of the chunk before have been read
+        first = false;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) af[u] = Ps[k0 + kq][16 * u + li];
+        for (int e = 0; e < 4; ++e) {
+          Ps[sk + e][srow] = -pa[c][e];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) bf[q] = Qs[k0 + kq][q * CHB + 16 * wave + li];
+          for (int q = 0; q < NQ; ++q) Qs[sk + e][q * CHB + srow] = qa[c][q][e];
+        }
+        __syncthreads();
+        if (decltype(prefetch)::value) {   // this chunk's registers are free: the same chunk of the next block column
+          const unsigned o = (unsigned)((kb + 1) * 4 + c) * 128u;
+          dag_load2(rs, pbase + o, pa[c][0], pa[c][1]);
+          dag_load2(rs, pbase + o + 16, pa[c][2], pa[c][3]);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+          for (int q = 0; q < NQ; ++q) {
+            dag_load2(rs, qbase[q] + o, qa[c][q][0], qa[c][q][1]);
+            dag_load2(rs, qbase[q] + o + 16, qa[c][q][2], qa[c][q][3]);
+          }
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[q][u] = MFMA_F64(af[u], bf[q], acc[q][u]);
-    }
-    if (more && !known) {
-      wait_avail((unsigned)((c + 1) >> 2));
-      if (!ok) return false;
-      fetch(c + 1);
-    }
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+          double af[4], bf[NQ];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) af[u] = Ps[k0 + kq][16 * u + li];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) bf[q] = Qs[k0 + kq][q * CHB + 16 * wave + li];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = MFMA_F64(af[u], bf[q], acc[q][u]);
+        }
+      }
+    };
+    if (pre)
+      body(std::true_type{});
+    else
+      body(std::false_type{});
+    have = pre;
   }
   __syncthreads();   // the staging area is free again
   return true;
 }
 
-// out^T = W C^T for the tile whose C^T sits in `c` (accumulator layout of dag_accumulate), W row-major in
-// R; the result goes through R to block (irow, j) of the matrix by coalesced write-through stores.
-__device__ __forceinline__ void dag_finish_tile(const d4 (&c)[4], chol_lds_t R, __amdgpu_buffer_rsrc_t rs, int ld, int irow,
-                                                int j, int tid) {
+// One block column (64 values of k) of one tile, for the two places where the diagonal chain waits for a
+// single late term: dag_block_fetch brings both operands into registers (all loads in flight together),
+// dag_block_apply<NC> multiplies them in, NC chunks of 16 per LDS fill (column operand k-major in the first
+// 16 NC rows of dagS, row operand k-major in Qbuf, which is dagR while that is free or the upper half of dagS).
+struct DagBlock {
+  double p[4][4], q[4][4];
+};
+__device__ __forceinline__ void dag_block_fetch(DagBlock& b, __amdgpu_buffer_rsrc_t rs, int ld, int j, int qrow, int kb,
+                                                int tid) {
+  const int srow = tid >> 2, sk = (tid & 3) * 4;
+  const unsigned pbase = (unsigned)(((int64_t)(j * CHB + srow) * ld + kb * CHB + sk) * 8);
+  const unsigned qbase = (unsigned)(((int64_t)(qrow * CHB + srow) * ld + kb * CHB + sk) * 8);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    dag_load2(rs, pbase + c * 128, b.p[c][0], b.p[c][1]);
+    dag_load2(rs, pbase + c * 128 + 16, b.p[c][2], b.p[c][3]);
+    dag_load2(rs, qbase + c * 128, b.q[c][0], b.q[c][1]);
+    dag_load2(rs, qbase + c * 128 + 16, b.q[c][2], b.q[c][3]);
+  }
+}
+template <int NC>
+__device__ __forceinline__ void dag_block_apply(const DagBlock& b, d4 (&acc)[4], double (*Qbuf)[CHB + 1], int tid) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int srow = tid >> 2, sk = (tid & 3) * 4;
+#pragma unroll
+  for (int c0 = 0; c0 < 4; c0 += NC) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dagS[16 * c + sk + e][srow] = -b.p[c0 + c][e];
+        Qbuf[16 * c + sk + e][srow] = b.q[c0 + c][e];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < 16 * NC; k0 += 4) {
+      double af[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) af[u] = dagS[k0 + kq][16 * u + li];
+      const double bf = Qbuf[k0 + kq][16 * wave + li];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = MFMA_F64(af[u], bf, acc[u]);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double dag_w(int a, int b, int r, int c);
+// L = C W^T for the tile whose C^T sits in `c` (accumulator layout of dag_accumulate).  W is read from dagR,
+// row-major (PACKED: as a worker loaded it) or in the layout dag_invert leaves it in; the result goes through
+// dagS to block (irow, j) of the matrix by coalesced write-through stores.  dagS must be free on entry; it may
+// be reused after the next barrier.
+template <bool PACKED>
+__device__ __forceinline__ void dag_finish_tile(const d4 (&c)[4], __amdgpu_buffer_rsrc_t rs, int ld, int irow, int j,
+                                                int tid) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   d4 o[4];
 #pragma unroll
@@ -2741,42 +2842,28 @@ __device__ __forceinline__ void dag_finish_tile(const d4 (&c)[4], chol_lds_t R, 
 #pragma unroll
     for (int u = 0; u <= up; ++u)   // W is lower triangular: blocks right of the diagonal are zero
 #pragma unroll
-      for (int t = 0; t < 4; ++t) o[up] = MFMA_F64(R[16 * up + li][16 * u + 4 * t + kq], c[u][t], o[up]);
+      for (int t = 0; t < 4; ++t) {
+        const double w = PACKED ? dagR[16 * up + li][16 * u + 4 * t + kq] : dag_w(up, u, li, 4 * t + kq);
+        o[up] = MFMA_F64(w, c[u][t], o[up]);
+      }
   }
-  __syncthreads();   // every wave has read W
 #pragma unroll
   for (int up = 0; up < 4; ++up)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) R[16 * wave + li][16 * up + 4 * t + kq] = o[up][t];
+    for (int t = 0; t < 4; ++t) dagS[16 * wave + li][16 * up + 4 * t + kq] = o[up][t];
   __syncthreads();
   const unsigned base = (unsigned)(((int64_t)irow * CHB * ld + (int64_t)j * CHB) * 8);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int id = tid + 256 * e;
     const int r = id >> 5, pc = (id & 31) * 2;
-    dag_store2(rs, base + (unsigned)(((int64_t)r * ld + pc) * 8), R[r][pc], R[r][pc + 1]);
+    dag_store2(rs, base + (unsigned)(((int64_t)r * ld + pc) * 8), dagS[r][pc], dagS[r][pc + 1]);
   }
-}
-
-// LDS of the single-launch factorisation (file scope: the non-inlined pieces of the diagonal task use it too).
-__shared__ double dagR[CHB][CHB + 1];   // in turn: staging of the accumulation, diagonal tile, W, result tile
-__shared__ double dag_rsd[CHB];
-__shared__ double dag_piv[16];
-__shared__ double dag_colb[2][CHB];
-__shared__ unsigned dag_word[4];
-__shared__ unsigned dag_role;
-
-// Entry (i, k) of the inverse of the 16 x 16 diagonal block `a` of the factor in dagR: strictly lower
-// entries are kept transposed above the diagonal of that block, the diagonal is dag_rsd.
-__device__ __forceinline__ double dag_dinv(int a, int i, int k) {
-  const double lo = dagR[16 * a + min(i, k)][16 * a + max(i, k)];
-  return i > k ? lo : (i == k ? dag_rsd[16 * a + i] : 0.0);
 }
 
 // One wave: right-looking factorisation of the 16-column sub-panel at c0 of the tile in dagR, one matrix row
 // per lane (the F step of chol_panel_kernel).  Returns 0, or 1 + the column of the first non-positive pivot.
-__device__ __forceinline__ int dag_f16(int c0) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ int dag_f16(int c0, int lane) {
   double a[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) a[c] = dagR[lane][c0 + c];
@@ -2812,9 +2899,9 @@ __device__ __forceinline__ int dag_f16(int c0) {
 
 // One wave: inverse of the 16 x 16 lower-triangular block at s0 by forward substitution, one column per lane;
 // row r of the block is fetched while row r-1 is summed (the empty asm keeps the compiler from issuing all
-// 120 loads at once).  The strictly lower part of the inverse goes, transposed, above the block's diagonal.
-__device__ __forceinline__ void dag_dinv16(int s0) {
-  const int lane = threadIdx.x & 63, cc = lane & 15;
+// 120 loads at once).  The inverse goes to dagDv as a full block (zeros above the diagonal).
+__device__ __forceinline__ void dag_dinv16(int s0, int lane) {
+  const int cc = lane & 15;
   double z[16], cur[16], nxt[16];
   z[0] = cc == 0 ? dag_rsd[s0] : 0.0;
   cur[0] = dagR[s0 + 1][s0];
@@ -2840,85 +2927,69 @@ __device__ __forceinline__ void dag_dinv16(int s0) {
   }
   if (lane < 16) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r)
-      if (r > cc) dagR[s0 + cc][s0 + r] = z[r];
+    for (int r = 0; r < 16; ++r) dagDv[s0 >> 4][r][cc] = z[r];
   }
 }
 
 // All four waves: W = L^-1 of the factorised tile in dagR, by block distance from the diagonal:
-// W_ab = -Dinv_a * sum_{m=b}^{a-1} L_am W_mb, W_bb = Dinv_b.  Blocks of W (and the sums before them) live
-// untransposed in the upper block (b, a); at the end W stands row-major in dagR in place of the factor.
-__device__ __forceinline__ void dag_invert() {
-  const int tid = threadIdx.x;
+// W_ab = -Dinv_a * sum_{m=b}^{a-1} L_am W_mb, W_bb = Dinv_b.  Block W_ab, a > b (and the sum before it), is
+// kept untransposed in the UPPER block (b, a) of dagR: W[16a + r][16b + c] = dagR[16b + r][16a + c]; the
+// diagonal blocks stay in dagDv.  dag_w reads W from that layout.
+__device__ __forceinline__ double dag_w(int a, int b, int r, int c) {   // W[16a + r][16b + c], a >= b
+  return a == b ? dagDv[a][r][c] : dagR[16 * b + r][16 * a + c];
+}
+__device__ __forceinline__ void dag_invert(int tid) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   chol_lds_t R = dagR;
-#pragma unroll 1
+#pragma unroll
   for (int dist = 1; dist < 4; ++dist) {
     if (wave < 4 - dist) {
       const int b = wave, a = wave + dist;
       d4 q = d4{0.0, 0.0, 0.0, 0.0};
-      for (int m = b; m < a; ++m)
+#pragma unroll
+      for (int mo = 0; mo < dist; ++mo) {
+        const int m = b + mo;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const double x = R[16 * a + li][16 * m + 4 * s + kq];                 // L_am[li][k]
-          const double y = m == b ? dag_dinv(b, 4 * s + kq, li)                  // W_mb[k][li]
-                                  : R[16 * b + 4 * s + kq][16 * m + li];
+          const double x = R[16 * a + li][16 * m + 4 * s + kq];                        // L_am[li][k]
+          const double y = mo == 0 ? dagDv[b][4 * s + kq][li] : R[16 * b + 4 * s + kq][16 * m + li];   // W_mb[k][li]
           q = MFMA_F64(x, y, q);
         }
+      }
+      d4 w = d4{0.0, 0.0, 0.0, 0.0};
+      // -Dinv_a * Q: Q goes from the accumulator layout to the B-operand layout through the block's own home
 #pragma unroll
       for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = q[t];
-    }
-    __syncthreads();
-    if (wave < 4 - dist) {
-      const int b = wave, a = wave + dist;
-      d4 w = d4{0.0, 0.0, 0.0, 0.0};
-      double y[4];
+      // (one wave wrote and reads the block: its LDS accesses execute in order, no barrier needed)
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int s = 0; s < 4; ++s) y[s] = R[16 * b + 4 * s + kq][16 * a + li];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) w = MFMA_F64(-dag_dinv(a, li, 4 * s + kq), y[s], w);
+      for (int s = 0; s < 4; ++s) w = MFMA_F64(-dagDv[a][li][4 * s + kq], R[16 * b + 4 * s + kq][16 * a + li], w);
 #pragma unroll
       for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = w[t];
     }
     __syncthreads();
   }
-  double wv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int idx = tid + 256 * e;
-    const int r = idx >> 6, c = idx & 63, a = r >> 4, b = c >> 4;
-    wv[e] = a > b ? R[16 * b + (r & 15)][16 * a + (c & 15)] : (a == b ? dag_dinv(a, r & 15, c & 15) : 0.0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int idx = tid + 256 * e;
-    R[idx >> 6][idx & 63] = wv[e];
-  }
-  __syncthreads();
 }
 
-// Everything of a diagonal task behind the accumulation, as ONE non-inlined function: factorisation of the
-// tile in dagR by 16-column sub-panels (see chol_panel_kernel; wave 1 inverts the diagonal 16 x 16 block of the
-// sub-panel before), then the inverse of the factor.  A function of its own has its own register allocation:
-// the long unrolled chains here do not crowd the accumulation loops of the kernel, and the callee-saved
-// registers are saved once per task.  Returns 0, or 1 + the column of the first non-positive pivot.
-__device__ __attribute__((noinline)) int dag_diag_tail(int j, int nb, unsigned* ctl) {
-  const int tid = threadIdx.x;
+// The factorisation of the tile in dagR by 16-column sub-panels (see chol_panel_kernel): wave 0 factorises a
+// sub-panel while wave 1 inverts the diagonal 16 x 16 block of the one before and waves 2, 3 update the tiles
+// further right; the tile column the next sub-panel needs is updated by all waves in between.  Returns 0, or
+// 1 + the column of the first non-positive pivot (meaningful in wave 0).
+__device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, int tid) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kq = lane >> 4;
   chol_lds_t R = dagR;
-  (void)j; (void)nb; (void)ctl; (void)lane;
+  (void)j; (void)nb; (void)ctl;
     int badcol = 0;
 #pragma unroll 1
     for (int ph = 0; ph <= 4; ++ph) {
       const int c0 = ph * 16;
       if (wave == 0) {
         if (ph < 4) {
-          const int bc = dag_f16(c0);
+          const int bc = dag_f16(c0, lane);
           if (bc && !badcol) badcol = bc;
         }
       } else if (wave == 1) {
-        if (ph >= 1) dag_dinv16(c0 - 16);
+        if (ph >= 1) dag_dinv16(c0 - 16, lane);
       } else {
         int n = wave - 2;
         if (ph >= 1) {
@@ -2941,25 +3012,20 @@ __device__ __attribute__((noinline)) int dag_diag_tail(int j, int nb, unsigned* 
       __syncthreads();
       if (ph == 0) { DAG_TRACE(j, 13) }
     }
-    DAG_TRACE(j, 3)
-    dag_invert();
   return badcol;
 }
 
-__global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ aug, int ld, int nb, unsigned aug_bytes,
+__global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ aug, int ld, int nb, unsigned aug_bytes,
                                                           double* __restrict__ Winv, int* __restrict__ info,
                                                           unsigned* __restrict__ ctl, int nchain) {
   chol_lds_t R = dagR;
-  unsigned* s_word = dag_word;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)aug, 0, (int)aug_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc((void*)Winv, 0, nb * CHB * CHB * (int)sizeof(double), 0x00020000);
   unsigned* rowready = ctl + DAG_SLOT;
-  const int ntasks = nb * (nb + 1) / 2;   // tiles (i, j), i = j+1 .. nb, column by column
-  // Roles.  The factorisation of a diagonal tile is one long chain of dependent fp64 operations; beside
-  // waves that keep the matrix pipe busy it runs three times slower.  So the first workgroup to arrive on
-  // each of the first `nchain` compute units takes diagonal tasks only and every other workgroup that lands
-  // on such a unit leaves at once; all remaining workgroups take the off-diagonal tiles.
+  // worker tasks: column j has rows j+2 .. nb in pairs, (nb - j) / 2 tasks
+  int ntasks = 0;
+  for (int jj = 0; jj < nb; ++jj) ntasks += (nb - jj) / 2;
   if (threadIdx.x == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));    // HW_ID[15:8]: engine, array, unit
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));             // XCC_ID[3:0]
@@ -2967,7 +3033,7 @@ __global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ a
     unsigned role = 0;
     if (atomicAdd(cu, 1u) == 0) {
       role = atomicAdd(ctl + 3, 1u) < (unsigned)nchain ? 2u : 1u;
-      __hip_atomic_store(cu + 1, role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dag_post(cu + 1, role);
     } else {
       for (unsigned spins = 0; (role = dag_poll(cu + 1)) == 0 && spins < DAG_SPIN_LIMIT; ++spins) __builtin_amdgcn_s_sleep(2);
       if (role == 2) role = 3;
@@ -2985,50 +3051,37 @@ __global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ a
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kq = lane >> 4;
     if (tid == 0) {
-      s_word[0] = atomicAdd(role == 2 ? ctl + 2 : ctl, 1u);
-      s_word[1] = dag_poll(ctl + 1);
+      dag_word[0] = atomicAdd(role == 2 ? ctl + 2 : ctl, 1u);
+      dag_word[1] = dag_poll(ctl + 1);
     }
     __syncthreads();
-    const int task = (int)s_word[0];
-    const bool stop = s_word[1] != 0;
+    const int task = (int)dag_word[0];
+    const bool stop = dag_word[1] != 0;
     __syncthreads();
     const bool diag = role == 2;
     if (task >= (diag ? nb : ntasks) || stop) return;
-    int j = diag ? task : 0, rem = diag ? 0 : task;
-    while (!diag && rem >= nb - j) {
-      rem -= nb - j;
-      ++j;
-    }
     const int r_own = 16 * wave + li;   // row of the tile this lane's accumulators belong to
     if (!diag) {
-      // ---------------------------------------------------------------- tile (i, j), i > j
-      const int i = j + 1 + rem;
-      d4 acc[1][4];
+      // ------------------------------------------------------------ tiles (i, j), (i+1, j); i = j+2, j+4, ...
+      int j = 0, rem = task;
+      while (rem >= (nb - j) / 2) {
+        rem -= (nb - j) / 2;
+        ++j;
+      }
+      const int i = j + 2 + 2 * rem;
+      const bool two = i + 1 <= nb;
+      const int i2 = two ? i + 1 : i;   // a lone last row is simply done twice
+      d4 acc[2][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
           acc[0][u][t] = aug[(int64_t)(i * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
-      const int qrow[1] = {i};
-      if (!dag_accumulate<1>(acc, &dagR[0][0], rs, ld, j, qrow, rowready, ctl, s_word, tid)) return;
-      // W_j
-      if (tid == 0) {
-        unsigned spins = 0, dead = 0;
-        while (dag_poll(rowready + (size_t)j * DAG_SLOT) < (unsigned)(j + 1)) {
-          if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
-            dead = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
+          acc[1][u][t] = aug[(int64_t)(i2 * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
         }
-        s_word[3] = dead;
-      }
-      __syncthreads();
-      if (s_word[3]) {
-        if (tid == 0) __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;   // uniform: every thread read the same word behind the barrier
-      }
-      if (i == j + 1) { DAG_TRACE(j, 8) }
+      const int qrow[2] = {i, i2};
+      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j, rowready, ctl, tid)) return;
+      if (!dag_wait(rowready, ctl, j, j, j, (unsigned)j + 1u, tid)) return;   // W_j
       {
         double wv[16];
 #pragma unroll
@@ -3045,18 +3098,23 @@ __global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ a
         }
       }
       __syncthreads();
-      if (i == j + 1) { DAG_TRACE(j, 9) }
-      dag_finish_tile(acc[0], R, rs, ld, i, j, tid);
-      if (i == j + 1) { DAG_TRACE(j, 10) }
+      // each tile is published as soon as it is out: the upper one may be what the diagonal chain needs next
+      dag_finish_tile<true>(acc[0], rs, ld, i, j, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (i == j + 1) { DAG_TRACE(j, 11) }
-      if (tid == 0)
-        __hip_atomic_store(rowready + (size_t)i * DAG_SLOT, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) dag_post(rowready + (size_t)i * DAG_SLOT, (unsigned)(j + 1));
+      if (two) {
+        dag_finish_tile<true>(acc[1], rs, ld, i2, j, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) dag_post(rowready + (size_t)i2 * DAG_SLOT, (unsigned)(j + 1));
+      }
       continue;
     }
     // ------------------------------------------------------------------ diagonal task of column j
-    d4 acc[1][4];
+    const int j = task;
+    DAG_TRACE(j, 0)
+    d4 acc[2][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -3064,9 +3122,23 @@ __global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ a
         const int c = 16 * u + 4 * t + kq;
         const double v = aug[(int64_t)(j * CHB + r_own) * ld + j * CHB + c];
         acc[0][u][t] = c <= r_own ? v : 0.0;   // only the lower triangle of A_jj is stored
+        acc[1][u][t] = aug[(int64_t)((j + 1) * CHB + r_own) * ld + j * CHB + c];
       }
-    const int qrow[1] = {j};
-    if (!dag_accumulate<1>(acc, &dagR[0][0], rs, ld, j, qrow, rowready, ctl, s_word, tid)) return;
+    {
+      // Both tiles up to block column j-2; then the diagonal tile's last term, L_{j,j-1}, which is what the
+      // chain waits for.  The second tile's last term, L_{j+1,j-1}, comes from a worker and is taken in behind
+      // the factorisation.
+      const int qrow[2] = {j, j + 1};
+      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j - 1, rowready, ctl, tid)) return;
+      DAG_TRACE(j, 8)
+      if (j > 0) {
+        if (!dag_wait(rowready, ctl, j, j, j, (unsigned)j, tid)) return;
+        DAG_TRACE(j, 9)
+        DagBlock blk;
+        dag_block_fetch(blk, rs, ld, j, j, j - 1, tid);
+        dag_block_apply<4>(blk, acc[0], dagR, tid);
+      }
+    }
     DAG_TRACE(j, 1)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -3077,25 +3149,49 @@ __global__ __launch_bounds__(256, 3) void chol_dag_kernel(double* __restrict__ a
       }
     __syncthreads();
     DAG_TRACE(j, 2)
-    {
-      const int badcol = dag_diag_tail(j, nb, ctl);
-      if (wave == 0 && badcol && lane == 0) atomicCAS(info, 0, j * CHB + badcol);
-    }
-    DAG_TRACE(j, 4)
-    {
+    // The second tile's accumulators wait in dagS meanwhile: the unrolled chains of the factorisation want
+    // every register they can get.
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int id = tid + 256 * e;
-        const int r = id >> 5, pc = (id & 31) * 2;
-        dag_store2(rw, (unsigned)((j * CHB * CHB + id * 2) * 8), R[r][pc], R[r][pc + 1]);
-      }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dagS[r_own][16 * u + 4 * t + kq] = acc[1][u][t];
+    asm volatile("" ::: "memory");
+    const int badcol = dag_factor(j, nb, ctl, tid);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[1][u][t] = dagS[r_own][16 * u + 4 * t + kq];
+    __syncthreads();   // dagS is about to be used for staging again
+    if (wave == 0 && badcol && lane == 0) atomicCAS(info, 0, j * CHB + badcol);
+    DAG_TRACE(j, 3)
+    dag_invert(tid);
+    DAG_TRACE(j, 4)
+    if (j > 0) {   // the second tile's last term (a prefetch across the inversion only gets spilled)
+      if (!dag_wait(rowready, ctl, j + 1, j + 1, j + 1, (unsigned)j, tid)) return;
+      DagBlock blk2;
+      dag_block_fetch(blk2, rs, ld, j, j + 1, j - 1, tid);
+      dag_block_apply<2>(blk2, acc[1], (double (*)[CHB + 1]) & dagS[32][0], tid);
     }
     DAG_TRACE(j, 5)
+    // W_j on its way out, L_{j+1,j} = C W^T behind it; one drain for both, the chain's flag first
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int id = tid + 256 * e;
+      const int r = id >> 5, pc = (id & 31) * 2;
+      const int a = r >> 4, b = pc >> 4;
+      const double w0 = a >= b ? dag_w(a, b, r & 15, pc & 15) : 0.0;
+      const double w1 = a >= b ? dag_w(a, b, r & 15, (pc & 15) + 1) : 0.0;
+      dag_store2(rw, (unsigned)((j * CHB * CHB + id * 2) * 8), w0, w1);
+    }
+    DAG_TRACE(j, 6)
+    dag_finish_tile<false>(acc[1], rs, ld, j + 1, j, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    DAG_TRACE(j, 6)
-    if (tid == 0)
-      __hip_atomic_store(rowready + (size_t)j * DAG_SLOT, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      dag_post(rowready + (size_t)(j + 1) * DAG_SLOT, (unsigned)(j + 1));
+      dag_post(rowready + (size_t)j * DAG_SLOT, (unsigned)(j + 1));
+    }
+    DAG_TRACE(j, 7)
   }
 }
 
@@ -3695,9 +3791,11 @@ int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SY
 #endif
 
 // 0: one launch per panel / trailing update; 1: the single-launch factorisation; -1: single launch from
-// CHOL_DAG_MIN_NB block columns on (below that the few launches of the first form are as fast)
-#define CHOL_DAG_MIN_NB 8
-static int g_chol_mode = 0;    // the single-launch form is opt-in until it is the faster one
+// CHOL_DAG_MIN_NB block columns on.  The single launch is bound by its chain of diagonal tasks (about 30 us
+// per block column); the multi-launch form pays panel + trailing update per column, which is less up to an
+// order of about 3300 (measured: 1.44 vs 1.47 ms at 3072, 1.76 vs 1.71 at 3584, 3.96 vs 3.03 at 6144).
+#define CHOL_DAG_MIN_NB 56
+static int g_chol_mode = -1;
 static int g_dag_chain = 0;   // compute units kept for the diagonal chain; 0: chosen from the order
 int ttk_chol_mode(int mode) {
   if (mode >= 100) {   // tuning: 100 + units
@@ -3751,7 +3849,7 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
     unsigned* ctl = (unsigned*)((char*)chol_ws + chol_ctl_offset(nb));
     if (hipMemsetAsync(ctl, 0, (size_t)chol_ctl_bytes(nb), st) != hipSuccess) return TTK_ELAUNCH;
     // every slot of the device gets a workgroup, so that each compute unit sees its first arrival at once
-    const int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(16, nb / 4));
+    const int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
     hipLaunchKernelGGL(chol_dag_kernel, dim3((unsigned)chol_dag_slots()), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes,
                        invL, info, ctl, nchain);
     int rc = ttk_launch_status();
