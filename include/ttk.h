@@ -177,7 +177,7 @@ int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_lef
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream);
 /* How ttk_chol_solve_f64 factorises (same call, same result up to rounding): 0 = one launch per
  * panel and trailing update; 1 = the whole factorisation as one launch of tile tasks that wait on
- * each other through progress words in the workspace; -1 (default) = 1 from 56 block columns (order 3584) on,
+ * each other through progress words in the workspace; -1 (default) = 1 from 32 block columns (order 2048) on,
  * where it is the faster one.
  * Returns the previous mode; any other argument only queries. */
 int ttk_chol_mode(int mode);

@@ -2938,41 +2938,68 @@ __device__ __forceinline__ void dag_dinv16(int s0, int lane) {
 __device__ __forceinline__ double dag_w(int a, int b, int r, int c) {   // W[16a + r][16b + c], a >= b
   return a == b ? dagDv[a][r][c] : dagR[16 * b + r][16 * a + c];
 }
+// Q_ab = sum_{m=b}^{a-1} L_am W_mb into the home of block (a, b) (one wave).
+template <int A, int B>
+__device__ __forceinline__ void dag_inv_sum(int li, int kq) {
+  d4 q = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = B; m < A; ++m)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double x = dagR[16 * A + li][16 * m + 4 * s + kq];                                       // L_am[li][k]
+      const double y = m == B ? dagDv[B][4 * s + kq][li] : dagR[16 * B + 4 * s + kq][16 * m + li];   // W_mb[k][li]
+      q = MFMA_F64(x, y, q);
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dagR[16 * B + kq + 4 * t][16 * A + li] = q[t];
+}
+// W_ab = -Dinv_a Q_ab in place (one wave; its LDS accesses execute in order, so the block can be written and
+// read back without a barrier when the same wave formed Q just before).
+template <int A, int B>
+__device__ __forceinline__ void dag_inv_fin(int li, int kq) {
+  asm volatile("" ::: "memory");
+  d4 w = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w = MFMA_F64(-dagDv[A][li][4 * s + kq], dagR[16 * B + 4 * s + kq][16 * A + li], w);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dagR[16 * B + kq + 4 * t][16 * A + li] = w[t];
+}
+// The inverse of the last diagonal block is not there yet when this starts (the factorisation has just
+// finished its last sub-panel): wave 1 forms it in the first phase, beside the blocks that do not need it.
 __device__ __forceinline__ void dag_invert(int tid) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
-  chol_lds_t R = dagR;
-#pragma unroll
-  for (int dist = 1; dist < 4; ++dist) {
-    if (wave < 4 - dist) {
-      const int b = wave, a = wave + dist;
-      d4 q = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int mo = 0; mo < dist; ++mo) {
-        const int m = b + mo;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double x = R[16 * a + li][16 * m + 4 * s + kq];                        // L_am[li][k]
-          const double y = mo == 0 ? dagDv[b][4 * s + kq][li] : R[16 * b + 4 * s + kq][16 * m + li];   // W_mb[k][li]
-          q = MFMA_F64(x, y, q);
-        }
-      }
-      d4 w = d4{0.0, 0.0, 0.0, 0.0};
-      // -Dinv_a * Q: Q goes from the accumulator layout to the B-operand layout through the block's own home
-#pragma unroll
-      for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = q[t];
-      // (one wave wrote and reads the block: its LDS accesses execute in order, no barrier needed)
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int s = 0; s < 4; ++s) w = MFMA_F64(-dagDv[a][li][4 * s + kq], R[16 * b + 4 * s + kq][16 * a + li], w);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) R[16 * b + kq + 4 * t][16 * a + li] = w[t];
-    }
-    __syncthreads();
+  if (wave == 0) {
+    dag_inv_sum<1, 0>(li, kq);
+    dag_inv_fin<1, 0>(li, kq);
+  } else if (wave == 1) {
+    dag_dinv16(48, lane);
+  } else if (wave == 2) {
+    dag_inv_sum<2, 1>(li, kq);
+    dag_inv_fin<2, 1>(li, kq);
+  } else {
+    dag_inv_sum<3, 2>(li, kq);
   }
+  __syncthreads();
+  if (wave == 0) {
+    dag_inv_fin<3, 2>(li, kq);
+  } else if (wave == 1) {
+    dag_inv_sum<2, 0>(li, kq);
+    dag_inv_fin<2, 0>(li, kq);
+  } else if (wave == 2) {
+    dag_inv_sum<3, 1>(li, kq);   // L_31 Dinv_1 + L_32 W_21
+    dag_inv_fin<3, 1>(li, kq);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    dag_inv_sum<3, 0>(li, kq);   // L_30 Dinv_0 + L_31 W_10 + L_32 W_20
+    dag_inv_fin<3, 0>(li, kq);
+  }
+  __syncthreads();
 }
 
 // The factorisation of the tile in dagR by 16-column sub-panels (see chol_panel_kernel): wave 0 factorises a
-// sub-panel while wave 1 inverts the diagonal 16 x 16 block of the one before and waves 2, 3 update the tiles
+// sub-panel while wave 1 inverts the diagonal 16 x 16 block of the one before (the last block is left to
+// dag_invert) and waves 2, 3 update the tiles
 // further right; the tile column the next sub-panel needs is updated by all waves in between.  Returns 0, or
 // 1 + the column of the first non-positive pivot (meaningful in wave 0).
 __device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, int tid) {
@@ -2981,13 +3008,11 @@ __device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, int tid)
   (void)j; (void)nb; (void)ctl;
     int badcol = 0;
 #pragma unroll 1
-    for (int ph = 0; ph <= 4; ++ph) {
+    for (int ph = 0; ph < 4; ++ph) {
       const int c0 = ph * 16;
       if (wave == 0) {
-        if (ph < 4) {
-          const int bc = dag_f16(c0, lane);
-          if (bc && !badcol) badcol = bc;
-        }
+        const int bc = dag_f16(c0, lane);
+        if (bc && !badcol) badcol = bc;
       } else if (wave == 1) {
         if (ph >= 1) dag_dinv16(c0 - 16, lane);
       } else {
@@ -3002,12 +3027,11 @@ __device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, int tid)
       if (ph == 0) { DAG_TRACE(j, 12) }
       if (ph == 1) { DAG_TRACE(j, 14) }
       if (ph == 2) { DAG_TRACE(j, 15) }
-      if (ph == 4) break;
+      if (ph == 3) break;
       {
         int n = wave;
-        if (ph < 3)
-          for (int ti = ph + 1; ti < 4; ++ti, ++n)
-            if (!(n & 3)) chol_tile_update(R, R, R, ti, ph + 1, c0, li, kq);
+        for (int ti = ph + 1; ti < 4; ++ti, ++n)
+          if (!(n & 3)) chol_tile_update(R, R, R, ti, ph + 1, c0, li, kq);
       }
       __syncthreads();
       if (ph == 0) { DAG_TRACE(j, 13) }
@@ -3173,7 +3197,13 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
       dag_block_apply<2>(blk2, acc[1], (double (*)[CHB + 1]) & dagS[32][0], tid);
     }
     DAG_TRACE(j, 5)
-    // W_j on its way out, L_{j+1,j} = C W^T behind it; one drain for both, the chain's flag first
+    // L_{j+1,j} = C W^T first: it is what the next diagonal task waits for.  W_j follows; the workers that wait
+    // for it feed the diagonal chain only a whole factorisation later.
+    dag_finish_tile<false>(acc[1], rs, ld, j + 1, j, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) dag_post(rowready + (size_t)(j + 1) * DAG_SLOT, (unsigned)(j + 1));
+    DAG_TRACE(j, 6)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int id = tid + 256 * e;
@@ -3183,14 +3213,9 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
       const double w1 = a >= b ? dag_w(a, b, r & 15, (pc & 15) + 1) : 0.0;
       dag_store2(rw, (unsigned)((j * CHB * CHB + id * 2) * 8), w0, w1);
     }
-    DAG_TRACE(j, 6)
-    dag_finish_tile<false>(acc[1], rs, ld, j + 1, j, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      dag_post(rowready + (size_t)(j + 1) * DAG_SLOT, (unsigned)(j + 1));
-      dag_post(rowready + (size_t)j * DAG_SLOT, (unsigned)(j + 1));
-    }
+    if (tid == 0) dag_post(rowready + (size_t)j * DAG_SLOT, (unsigned)(j + 1));
     DAG_TRACE(j, 7)
   }
 }
@@ -3791,10 +3816,11 @@ int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SY
 #endif
 
 // 0: one launch per panel / trailing update; 1: the single-launch factorisation; -1: single launch from
-// CHOL_DAG_MIN_NB block columns on.  The single launch is bound by its chain of diagonal tasks (about 30 us
+// CHOL_DAG_MIN_NB block columns on.  The single launch is bound by its chain of diagonal tasks (about 28 us
 // per block column); the multi-launch form pays panel + trailing update per column, which is less up to an
-// order of about 3300 (measured: 1.44 vs 1.47 ms at 3072, 1.76 vs 1.71 at 3584, 3.96 vs 3.03 at 6144).
-#define CHOL_DAG_MIN_NB 56
+// order of about 2000 (measured, multi vs single: 0.67 / 0.68 ms at 1536, 0.91 / 0.90 at 2048, 2.11 / 1.80 at
+// 4096, 3.97 / 2.89 at 6144).
+#define CHOL_DAG_MIN_NB 32
 static int g_chol_mode = -1;
 static int g_dag_chain = 0;   // compute units kept for the diagonal chain; 0: chosen from the order
 int ttk_chol_mode(int mode) {

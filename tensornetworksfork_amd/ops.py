@@ -351,7 +351,7 @@ def chol_solve_gram(ws, b, w=None, scale=None, ridge=0.0):
 
 def chol_mode(mode):
     """How the Cholesky solves factorise: 0 one launch per panel / trailing update, 1 the whole
-    factorisation as one launch of tile tasks, -1 (default) the latter from 56 block columns on.
+    factorisation as one launch of tile tasks, -1 (default) the latter from 32 block columns on.
     Returns the previous mode; see ttk_chol_mode."""
     return int(_lib.lib().ttk_chol_mode(int(mode)))
 

@@ -235,6 +235,44 @@ def test_cholesky_solve(S, C, rl, p, rr):
 
 
 @gpu
+@pytest.mark.parametrize("n", [40, 64, 130, 512, 1000, 2304])
+def test_cholesky_single_launch_matches_multi_launch(n):
+    """The two forms of the factorisation (one launch per panel / trailing update; one launch of tile tasks
+    that wait on each other through progress words) against LAPACK and against each other: solution, pivot
+    report for a matrix that is not positive definite, and the same bits on every run (a stale read between
+    workgroups would show here first).  Orders below, at and above multiples of the 64 block."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(70 + n)
+    M = torch.randn(n, n + 32, generator=g, dtype=torch.float64)
+    A = (M @ M.T / (n + 32) + 0.05 * torch.eye(n, dtype=torch.float64))
+    b = torch.randn(n, generator=g, dtype=torch.float64)
+    scale = A.diagonal().abs().mean()
+    ref = torch.linalg.solve(A / scale, -b / scale)
+    Ad, bd = A.to(dev), b.to(dev)
+    bad = A.clone()
+    k = (2 * n) // 3
+    bad[k, k] = -1.0     # leading minor of order k+1 is not positive definite
+    badd = bad.to(dev)
+    out = {}
+    old = ops.chol_mode(-1)
+    try:
+        for mode in (0, 1):
+            ops.chol_mode(mode)
+            x, info = ops.chol_solve_dense(Ad, bd)
+            assert int(info.item()) == 0
+            assert G.rel_err(x, ref) < 1e-10, (n, mode)
+            for _ in range(4):
+                assert torch.equal(ops.chol_solve_dense(Ad, bd)[0], x), (n, mode)
+            _, info_bad = ops.chol_solve_dense(badd, bd)
+            out[mode] = (x, int(info_bad.item()))
+    finally:
+        ops.chol_mode(old)
+    assert out[0][1] == out[1][1] == k + 1
+    assert G.rel_err(out[1][0], out[0][0]) < 1e-11
+
+
+@gpu
 @pytest.mark.parametrize("m,n", [(192, 32), (6, 6), (36, 32), (17, 32), (12, 4), (5, 1), (1, 3), (300, 48), (64, 64)])
 def test_qr_matches_lapack(m, n):
     """One-workgroup Householder QR against torch.linalg.qr on the CPU (same sign convention)."""

@@ -20,7 +20,7 @@ cw = ops._chol_ws[(A.device, n)]
 off = ((nb + 1) * 64 * nb * 64 + nb * 64 * 64) * 8
 off = (off + 255) // 256 * 256 + (nb + 2) * 128 + 4096 * 4
 tr = cw.view(torch.int64)[off // 8: off // 8 + nb * 16].reshape(nb, 16).cpu().double() / 100.0   # microseconds
-names = ["acc->lds", "F loop", "wait+fetch+invert", "tile2 last term", "W stores", "finish+publish"]
+names = ["acc->lds", "F loop", "invert", "tile2 last term", "finish+publish L", "publish W"]
 pairs = [(1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7)]
 lo, hi = min(8, nb - 2), nb - 2
 print(f"n={n} nb={nb} total {tr[nb - 1, 7] - tr[0, 1]:.1f} us; per column {(tr[hi, 1] - tr[lo, 1]) / (hi - lo):.2f} us (columns {lo}..{hi})")
@@ -30,12 +30,12 @@ for name, (a, c) in zip(names, pairs):
 for name, (a, c) in [("  phase A0 (F0 alone)", (2, 12)), ("  phase B0", (12, 13)), ("  phase A1", (13, 14)), ("  B1+A2", (14, 15))]:
     d = tr[lo:hi, c] - tr[lo:hi, a]
     print(f"  {name:22s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f}")
-d = tr[lo + 1:hi + 1, 1] - tr[lo:hi, 7]
+d = tr[lo + 1:hi + 1, 1] - tr[lo:hi, 6]
 print(f"  {'L out -> next acc done':22s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f}")
 
 import numpy as np
 per = (tr[1:, 1] - tr[:-1, 1]).numpy()
-nxt = (tr[1:, 1] - tr[:-1, 7]).numpy()
+nxt = (tr[1:, 1] - tr[:-1, 6]).numpy()
 t2 = (tr[:, 6] - tr[:, 5]).numpy()
 for a in range(0, nb - 1, 8):
     b = min(nb - 1, a + 8)
