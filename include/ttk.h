@@ -268,6 +268,14 @@ int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t 
 int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
 int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream);
+
+/* Right-hand side / J^T u of a site with many features (16 <= p <= 256; a conv column has one per patch):
+ *   b (rl,p,rr) (+)= sum_s GL[s,l] X[s,pp] R[s,r],   GL (S,rl) = the gradient-weighted left factor (ttk_gl_f64)
+ * i.e. the einsum of get_A_b / get_b (tensor/network.py:205-217, 258-291) after the conv feature contraction
+ * (tensor/layers.py:839-872), features first.  ws: ttk_rhs_feature_ws_bytes(S, rl, p, rr) bytes of slab partials. */
+int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr);
+int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
+                        int accumulate, void* ws, int64_t ws_bytes, void* stream);
 int ttk_dense_scale_f64(const double* A, int D, double* scale, void* stream);
 int ttk_chol_prepare_dense_f64(const double* A, int D, const double* scale, double ridge, const double* b, const double* w,
                                void* chol_ws, void* stream);

@@ -391,6 +391,156 @@ __global__ __launch_bounds__(256) void dense_to_chol_kernel(const double* __rest
 }
 
 // rows of X a workgroup of conv_feature_kernel stages (its LDS image stays below 60 KiB)
+
+// ---------------------------------------------------------------------------------------
+// Right-hand side / J^T u of a site with many features (16 <= p <= 256), features first:
+//   b[l, pp, r] = sum_s X[s, pp] * (GL[s, l] R[s, r]),      GL[s, l] = sum_c g[s, c] L[s, c, l]
+// as a GEMM over the samples with rows pp and columns (l, r): the feature rows of a chunk of samples are
+// staged once per workgroup and serve all its output columns, whereas the three-factor kernel of the few-feature
+// sites would stream every slab of samples once per 96 output columns (33 times at 48 x 65 x 48).
+// A wave owns one 16-column tile (l, r0 .. r0+15) and all ceil(p / 16) row tiles; its right operand
+// GL[s, l] R[s, r0 + j] is formed while the chunk is staged, so the inner loop is one LDS read per operand and
+// the MFMAs.  Grid = (groups of four column tiles, slabs of samples); every slab writes its own partial result,
+// a second kernel adds the slabs in fixed order.
+// ---------------------------------------------------------------------------------------
+template <int PTC>   // row tiles a wave can hold: p <= 16 PTC
+__global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __restrict__ GL, const double* __restrict__ X,
+                                                              const double* __restrict__ R, double* __restrict__ partial,
+                                                              int64_t S, int rl, int p, int rr, int64_t slab_len) {
+  constexpr int CH = PTC == 4 ? 32 : 256 / PTC;   // samples per chunk
+  constexpr int PW = 16 * PTC + 16;       // LDS row of a sample's features: = 16 mod 32 doubles
+  constexpr int XQ = CH * PTC / 16;       // prefetch registers per thread: CH * 16 PTC / 256
+  constexpr int BQ = CH / 4;              // 4 waves x CH x 16 / 256
+  extern __shared__ double sm[];
+  double* Xs = sm;                        // [CH][PW]
+  double* Bs = sm + CH * PW;              // [4][CH][16]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+  const int nrt = (rr + 15) >> 4, pt = (p + 15) >> 4;
+  const int64_t s_begin = (int64_t)blockIdx.y * slab_len;
+  const int64_t s_end = min(S, s_begin + slab_len);
+  const int64_t D = (int64_t)rl * p * rr;
+  double* dst = partial + (int64_t)blockIdx.y * D;
+  const int jt = blockIdx.x * 4 + wave;
+  const bool active = jt < rl * nrt;
+  const int lw = active ? jt / nrt : 0, r0 = active ? (jt - lw * nrt) * 16 : 0;
+  // feature columns past p stay zero for the whole launch
+  for (int e = tid; e < CH * PW; e += 256) Xs[e] = 0.0;
+  // staging maps.  X: the chunk is CH * p consecutive doubles; element tid + 256 q goes to row (e / p), column (e % p).
+  int xdst[XQ];
+  {
+    int r = tid / p, c = tid - r * p;
+    const int dr = 256 / p, dc = 256 - dr * p;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      xdst[q] = (tid + 256 * q < CH * p) ? r * PW + c : -1;
+      c += dc;
+      r += dr;
+      if (c >= p) {
+        c -= p;
+        ++r;
+      }
+    }
+  }
+  // B: element tid + 256 q = (wave bw, sample k, column j) with j fastest
+  const int bj = tid & 15;
+  double px[XQ], pg[BQ], pr[BQ];
+  auto fetch = [&](int64_t c0) {
+    const int nvalid = (int)min((int64_t)CH, s_end - c0);
+    const double* x0 = X + c0 * p + tid;
+    const int lx = nvalid * p - 1 - tid;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) px[q] = x0[max(min(256 * q, lx), -tid)];
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const int e = tid + 256 * q;
+      const int bw = e / (CH * 16), k = (e >> 4) % CH;
+      const int jw = blockIdx.x * 4 + bw;
+      const int l = min(jw / nrt, rl - 1), rb = (jw % nrt) * 16 + bj;
+      const int64_t srow = c0 + min(k, nvalid - 1);
+      pg[q] = GL[srow * rl + l];
+      pr[q] = R[srow * rr + min(rb, rr - 1)];
+    }
+  };
+  d4 acc[PTC];
+#pragma unroll
+  for (int u = 0; u < PTC; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+  if (s_begin < s_end) fetch(s_begin);
+  for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
+    const int nvalid = (int)min((int64_t)CH, s_end - c0);
+    __syncthreads();   // every wave is done with the previous chunk (and, the first time, the zero fill is complete)
+    {
+      const int lx = nvalid * p - 1 - tid;
+#pragma unroll
+      for (int q = 0; q < XQ; ++q)
+        if (xdst[q] >= 0) Xs[xdst[q]] = 256 * q <= lx ? px[q] : 0.0;
+#pragma unroll
+      for (int q = 0; q < BQ; ++q) {
+        const int e = tid + 256 * q;
+        const int bw = e / (CH * 16), k = (e >> 4) % CH;
+        const int jw = blockIdx.x * 4 + bw;
+        const bool ok = k < nvalid && jw < rl * nrt && (jw % nrt) * 16 + bj < rr;
+        Bs[e] = ok ? pg[q] * pr[q] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (c0 + CH < s_end) fetch(c0 + CH);
+    if (active) {
+      const double* bw_ = Bs + wave * CH * 16;
+#pragma unroll 2
+      for (int ks = 0; ks < CH / 4; ++ks) {
+        const double bf = bw_[(ks * 4 + kq) * 16 + li];
+        const double* xrow = Xs + (ks * 4 + kq) * PW + li;
+#pragma unroll
+        for (int u = 0; u < PTC; ++u)
+          if (u < pt) acc[u] = MFMA_F64(xrow[16 * u], bf, acc[u]);
+      }
+    }
+  }
+  if (active && r0 + li < rr) {
+#pragma unroll
+    for (int u = 0; u < PTC; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pp = 16 * u + kq + 4 * t;
+        if (u < pt && pp < p) dst[((int64_t)lw * p + pp) * rr + r0 + li] = acc[u][t];
+      }
+  }
+}
+
+// out[i] (+)= sum over the slabs of partial[slab][i], slabs added in fixed order
+__global__ __launch_bounds__(256) void dense_reduce_slabs_kernel(const double* __restrict__ partial, int nslabs, int64_t n,
+                                                                  double* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a0 = 0.0, a1 = 0.0;
+  int k = 0;
+  for (; k + 1 < nslabs; k += 2) {
+    a0 += partial[(int64_t)k * n + i];
+    a1 += partial[(int64_t)(k + 1) * n + i];
+  }
+  if (k < nslabs) a0 += partial[(int64_t)k * n + i];
+  out[i] = (accumulate ? out[i] : 0.0) + (a0 + a1);
+}
+
+struct RhsFeatDims {
+  int ptc, ngroups, nslabs;
+  int64_t slab_len;
+};
+static RhsFeatDims rhs_feature_dims(int64_t S, int rl, int p, int rr) {
+  RhsFeatDims d;
+  d.ptc = p <= 64 ? 4 : (p <= 128 ? 8 : 16);
+  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
+  d.ngroups = (rl * ((rr + 15) / 16) + 3) / 4;
+  int ns = 1024 / d.ngroups;
+  const int64_t maxs = (S + 4 * ch - 1) / (4 * ch);   // at least four chunks per slab
+  if (ns > maxs) ns = (int)maxs;
+  if (ns > 64) ns = 64;
+  if (ns < 1) ns = 1;
+  d.slab_len = ((S + ns - 1) / ns + ch - 1) / ch * ch;
+  d.nslabs = (int)((S + d.slab_len - 1) / d.slab_len);
+  return d;
+}
+
 static int conv_feature_rows(int px, int nab) {
   const int64_t room = 60 * 1024 / 8 - (int64_t)px * nab;
   int64_t rb = room / (px | 1);
@@ -528,6 +678,47 @@ int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int
   if (!A || !B || !Cm || n < 1 || D1 < 1 || D2 < 1) return TTK_EINVAL;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((D2 + 63) / 64), (unsigned)((D1 + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, A, B, Cm, n, D1, D2, accumulate);
+  return dense_status();
+}
+
+int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr) {
+  if (S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
+  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
+  return (int64_t)d.nslabs * rl * p * rr * (int64_t)sizeof(double);
+}
+
+int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
+                        int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+  if (!GL || !X || !R || !b || !ws || S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
+  if (ws_bytes < ttk_rhs_feature_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
+  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)d.ngroups, (unsigned)d.nslabs);
+  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
+  const size_t lds = ((size_t)ch * (16 * d.ptc + 16) + (size_t)4 * ch * 16) * sizeof(double);
+  static bool allowed = false;   // more than 64 KiB of dynamic LDS needs the attribute once per process
+  if (!allowed) {
+    if (hipFuncSetAttribute((const void*)rhs_feature_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)rhs_feature_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)rhs_feature_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess)
+      return TTK_ELAUNCH;
+    allowed = true;
+  }
+  double* partial = (double*)ws;
+  if (d.ptc == 4)
+    hipLaunchKernelGGL(rhs_feature_kernel<4>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  else if (d.ptc == 8)
+    hipLaunchKernelGGL(rhs_feature_kernel<8>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  else
+    hipLaunchKernelGGL(rhs_feature_kernel<16>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  int rc = dense_status();
+  if (rc != TTK_OK) return rc;
+  const int64_t D = (int64_t)rl * p * rr;
+  hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)partial,
+                     d.nslabs, D, b, accumulate);
   return dense_status();
 }
 

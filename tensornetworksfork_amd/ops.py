@@ -439,6 +439,32 @@ def gl(g, L):
     return out
 
 
+_rhsf_ws = {}
+
+
+def rhs_feature(L, X, R, g, out=None):
+    """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r] for a site with many features
+    (DENSE_MIN_P <= p <= DENSE_MAX_P), features first; with `out` given the result is added to it."""
+    S, C, rl = L.shape
+    p, rr = X.shape[1], R.shape[1]
+    GL = gl(g, L)
+    nbytes = int(_lib.lib().ttk_rhs_feature_ws_bytes(S, rl, p, rr))
+    if nbytes < 0:
+        raise _lib.TTKError("ttk_rhs_feature_ws_bytes: invalid extents")
+    key = (L.device, nbytes)
+    ws = _rhsf_ws.get(key)
+    if ws is None:
+        _rhsf_ws.clear()
+        ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
+        _rhsf_ws[key] = ws
+    acc = out is not None
+    b = out if acc else torch.empty((rl, p, rr), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_rhs_feature_f64(GL.data_ptr(), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(b, "b", (rl, p, rr)),
+                                        S, rl, p, rr, int(acc), ws.data_ptr(), nbytes, _stream(L))
+    _lib.check(rc, "ttk_rhs_feature_f64")
+    return b
+
+
 def conv_feature(X, Fc):
     """G (ca, cb, S, P) = X (S, P, px) . Fc (ca, px, cb); X float64 or float32 (read as it is)."""
     S, P, px = X.shape

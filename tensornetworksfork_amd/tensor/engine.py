@@ -123,6 +123,19 @@ def _ones_col(S, device):
     return _ONES[key]
 
 
+def _rhs_features_first(rl, p, rr):
+    """Whether J^T u of a Khatri-Rao term goes to the features-first kernel.  The three-factor kernel streams
+    every slab of samples once per 4 x 96 output columns ("passes"); the features-first one stages a chunk once
+    for all its columns but needs enough 16-column tiles (l, r-tile) to fill the device.  Measured (S = 50 000,
+    C = 9): 48 x 65 x 48 (33 passes) 1.4 -> 0.5 ms; 24 x 50 x 24 (7 passes) and the edge sites (one bond of 1)
+    are faster on the three-factor kernel."""
+    if not TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P:
+        return False
+    blocks = (((rl + 15) // 16 + 1) // 2) * (((p * rr + 15) // 16 + 2) // 3)
+    passes = (blocks + 3) // 4
+    return passes >= 12 and rl * ((rr + 15) // 16) >= 24
+
+
 class LocalProblem:
     """The normal equations of one train node for a bound data set.
 
@@ -160,7 +173,10 @@ class LocalProblem:
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
         for (L, X, R) in self.terms:
-            if not ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
+            if _rhs_features_first(L.shape[2], X.shape[1], R.shape[1]):
+                # many features and a wide output: the GEMM over the samples with the features as rows
+                out = ops.rhs_feature(L, X, R, g) if out is None else ops.rhs_feature(L, X, R, g, out=out)
+            elif not ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
                 # a sample row too wide for the right-hand-side kernel's LDS chunk: features last,
                 # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L, as one transposed product over the samples
                 S, rl, rr = L.shape[0], L.shape[2], R.shape[1]

@@ -88,6 +88,10 @@ def rhs(L, X, R, g, out=None):
     return r if out is None else out.add_(r)
 
 
+def rhs_feature(L, X, R, g, out=None):
+    return rhs(L, X, R, g, out=out)
+
+
 def jvp(L, X, R, H, v):
     u = torch.einsum('scl,sp,sr,lpr->sc', L, X, R, v)
     return torch.einsum('scd,sd->sc', H, u)
@@ -272,7 +276,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported rhs_feature").split()
 
 
 def install(monkeypatch):

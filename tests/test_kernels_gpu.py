@@ -235,6 +235,23 @@ def test_cholesky_solve(S, C, rl, p, rr):
 
 
 @gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", [(300, 1, 4, 16, 4), (1000, 3, 24, 50, 24), (777, 9, 48, 65, 48), (129, 2, 1, 17, 5),
+                                         (500, 1, 7, 130, 9), (260, 2, 3, 256, 2), (64, 1, 5, 33, 1)])
+def test_rhs_feature_matches_oracle(S, C, rl, p, rr):
+    """The features-first right-hand side of sites with many features against the oracle's einsum, plain and
+    accumulating; extents below / at / above the 16-wide tiles, ragged sample counts (last chunk, last slab)."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    L, X, R, g = _rand((S, C, rl), 81), _rand((S, p), 82), _rand((S, rr), 83), _rand((S, C), 84)
+    ref = torch.einsum('sc,scl,sp,sr->lpr', g, L, X, R)
+    b = ops.rhs_feature(L.to(dev), X.to(dev), R.to(dev), g.to(dev))
+    assert G.rel_err(b, ref) < TOL
+    b2 = ops.rhs_feature(L.to(dev), X.to(dev), R.to(dev), g.to(dev), out=b.clone())
+    assert G.rel_err(b2, 2 * ref) < TOL
+    assert torch.equal(ops.rhs_feature(L.to(dev), X.to(dev), R.to(dev), g.to(dev)), b)   # fixed summation order
+
+
+@gpu
 @pytest.mark.parametrize("n", [40, 64, 130, 512, 1000, 2304])
 def test_cholesky_single_launch_matches_multi_launch(n):
     """The two forms of the factorisation (one launch per panel / trailing update; one launch of tile tasks
