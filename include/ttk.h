@@ -170,7 +170,8 @@ int ttk_solve_rhs_f64(const double* b, const double* w, const double* scale, dou
  *                            -(b/scale[0] + ridge*w)        (network.py:301-302,312-313,315)
  *   ttk_chol_solve_f64    -> x (n) = solution; info[0] (device int) = 0, or the 1-based order
  *                            of the first non-positive pivot (torch.linalg.LinAlgError in
- *                            the reference, network.py:481-484). */
+ *                            the reference, network.py:481-484), or -1 when the single-launch
+ *                            factorisation gave up waiting (x is then not a solution). */
 int64_t ttk_chol_ws_bytes(int n);
 int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
                          const double* b, const double* w, void* chol_ws, void* stream);
@@ -179,7 +180,10 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
  * panel and trailing update; 1 = the whole factorisation as one launch of tile tasks that wait on
  * each other through progress words in the workspace; -1 (default) = 1 from 32 block columns (order 2048) on,
  * where it is the faster one.
- * Returns the previous mode; any other argument only queries. */
+ * Returns the previous mode; any other argument only queries.  Two ranges tune the single launch:
+ * 100 + u keeps u compute units for its diagonal chain (100: chosen from the order), 1000 + k lets a
+ * waiting lane give up after k polls (1000: the default of two million), which aborts the launch with
+ * info = -1 and is how the tests check that every wait ends. */
 int ttk_chol_mode(int mode);
 
 /* Reduced Householder QR of a row-major (m,n) matrix in one workgroup, LAPACK sign

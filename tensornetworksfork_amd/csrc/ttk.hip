@@ -2665,13 +2665,14 @@ __device__ __forceinline__ void dag_store2(__amdgpu_buffer_rsrc_t r, unsigned of
 // out of patience and aborted it).  need >= 1.
 __device__ __forceinline__ unsigned dag_wait(unsigned* rowready, unsigned* ctl, int ra, int rb, int rc, unsigned need,
                                              int tid) {
+  const unsigned spin_limit = ctl[4];   // written by the host before the launch, constant during it
   if (tid == 0) {
     unsigned a = 0, spins = 0;
     for (;;) {
       a = min(dag_poll(rowready + (size_t)ra * DAG_SLOT), dag_poll(rowready + (size_t)rb * DAG_SLOT));
       if (rc != rb) a = min(a, dag_poll(rowready + (size_t)rc * DAG_SLOT));
       if (a >= need) break;
-      if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > DAG_SPIN_LIMIT)) {
+      if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {
         dag_post(ctl + 1, 1u);
         a = 0;
         break;
@@ -3083,7 +3084,11 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
     const bool stop = dag_word[1] != 0;
     __syncthreads();
     const bool diag = role == 2;
-    if (task >= (diag ? nb : ntasks) || stop) return;
+    if (stop) {   // a wait somewhere ran out of patience: the result is not a factorisation
+      if (tid == 0) atomicCAS(info, 0, -1);
+      return;
+    }
+    if (task >= (diag ? nb : ntasks)) return;
     const int r_own = 16 * wave + li;   // row of the tile this lane's accumulators belong to
     if (!diag) {
       // ------------------------------------------------------------ tiles (i, j), (i+1, j); i = j+2, j+4, ...
@@ -3104,8 +3109,11 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
           acc[1][u][t] = aug[(int64_t)(i2 * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
         }
       const int qrow[2] = {i, i2};
-      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j, rowready, ctl, tid)) return;
-      if (!dag_wait(rowready, ctl, j, j, j, (unsigned)j + 1u, tid)) return;   // W_j
+      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j, rowready, ctl, tid) ||
+          !dag_wait(rowready, ctl, j, j, j, (unsigned)j + 1u, tid)) {   // ... and W_j
+        if (tid == 0) atomicCAS(info, 0, -1);
+        return;
+      }
       {
         double wv[16];
 #pragma unroll
@@ -3153,10 +3161,16 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
       // chain waits for.  The second tile's last term, L_{j+1,j-1}, comes from a worker and is taken in behind
       // the factorisation.
       const int qrow[2] = {j, j + 1};
-      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j - 1, rowready, ctl, tid)) return;
+      if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j - 1, rowready, ctl, tid)) {
+        if (tid == 0) atomicCAS(info, 0, -1);
+        return;
+      }
       DAG_TRACE(j, 8)
       if (j > 0) {
-        if (!dag_wait(rowready, ctl, j, j, j, (unsigned)j, tid)) return;
+        if (!dag_wait(rowready, ctl, j, j, j, (unsigned)j, tid)) {
+          if (tid == 0) atomicCAS(info, 0, -1);
+          return;
+        }
         DAG_TRACE(j, 9)
         DagBlock blk;
         dag_block_fetch(blk, rs, ld, j, j, j - 1, tid);
@@ -3191,7 +3205,10 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
     dag_invert(tid);
     DAG_TRACE(j, 4)
     if (j > 0) {   // the second tile's last term (a prefetch across the inversion only gets spilled)
-      if (!dag_wait(rowready, ctl, j + 1, j + 1, j + 1, (unsigned)j, tid)) return;
+      if (!dag_wait(rowready, ctl, j + 1, j + 1, j + 1, (unsigned)j, tid)) {
+        if (tid == 0) atomicCAS(info, 0, -1);
+        return;
+      }
       DagBlock blk2;
       dag_block_fetch(blk2, rs, ld, j, j + 1, j - 1, tid);
       dag_block_apply<2>(blk2, acc[1], (double (*)[CHB + 1]) & dagS[32][0], tid);
@@ -3823,7 +3840,12 @@ int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SY
 #define CHOL_DAG_MIN_NB 32
 static int g_chol_mode = -1;
 static int g_dag_chain = 0;   // compute units kept for the diagonal chain; 0: chosen from the order
+static int g_dag_spin_limit = DAG_SPIN_LIMIT;
 int ttk_chol_mode(int mode) {
+  if (mode >= 1000) {   // testing: polls before a waiting lane gives up (1000 restores the default)
+    g_dag_spin_limit = mode > 1000 ? mode - 1000 : (int)DAG_SPIN_LIMIT;
+    return g_chol_mode;
+  }
   if (mode >= 100) {   // tuning: 100 + units
     g_dag_chain = mode - 100;
     return g_chol_mode;
@@ -3874,10 +3896,13 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
     // every word the kernel polls or counts starts at zero
     unsigned* ctl = (unsigned*)((char*)chol_ws + chol_ctl_offset(nb));
     if (hipMemsetAsync(ctl, 0, (size_t)chol_ctl_bytes(nb), st) != hipSuccess) return TTK_ELAUNCH;
+    if (hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), g_dag_spin_limit, 1, st) != hipSuccess) return TTK_ELAUNCH;
     // every slot of the device gets a workgroup, so that each compute unit sees its first arrival at once
-    const int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
-    hipLaunchKernelGGL(chol_dag_kernel, dim3((unsigned)chol_dag_slots()), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes,
-                       invL, info, ctl, nchain);
+    const int slots = chol_dag_slots();
+    int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
+    nchain = max(1, min(nchain, slots / 16));   // most of the device must stay with the workers
+    hipLaunchKernelGGL(chol_dag_kernel, dim3((unsigned)slots), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes, invL, info,
+                       ctl, nchain);
     int rc = ttk_launch_status();
     if (rc != TTK_OK) return rc;
     return chol_back_substitute(st, aug, ld, nb, invL, x, n);   // invL already holds the inverses

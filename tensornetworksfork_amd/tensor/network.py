@@ -424,6 +424,9 @@ class TensorNetwork:
         if bad != 0:
             for n, t, labels, left, right in snapshot:
                 n.tensor, n.dim_labels, n.left_labels, n.right_labels = t, labels, left, right
+            if bad < 0:
+                raise RuntimeError("ttk_chol_solve_f64: the single-launch factorisation was aborted (a workgroup waited "
+                                   "for a tile beyond its limit); the update has been undone")
             raise torch.linalg.LinAlgError(
                 "linalg.cholesky: The factorization could not be completed because the input is not "
                 f"positive-definite (the leading minor of order {bad} is not positive-definite).")

@@ -290,6 +290,32 @@ def test_cholesky_single_launch_matches_multi_launch(n):
 
 
 @gpu
+def test_cholesky_single_launch_gives_up_cleanly():
+    """Every wait inside the single-launch factorisation is bounded: with the patience of a waiting lane cut to
+    a handful of polls the launch aborts itself (info = -1) instead of hanging, and the next solve is fine."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    n = 2304
+    g = torch.Generator().manual_seed(5)
+    M = torch.randn(n, n + 32, generator=g, dtype=torch.float64)
+    A = (M @ M.T / (n + 32) + 0.05 * torch.eye(n, dtype=torch.float64)).to(dev)
+    b = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    old = ops.chol_mode(1)
+    try:
+        ops.chol_mode(1000 + 1)
+        _, info = ops.chol_solve_dense(A, b)
+        assert int(info.item()) == -1
+        ops.chol_mode(1000)
+        x, info = ops.chol_solve_dense(A, b)
+        assert int(info.item()) == 0
+        scale = A.diagonal().abs().mean()
+        assert (((A / scale) @ x + b / scale).norm() / (b / scale).norm()).item() < 1e-10
+    finally:
+        ops.chol_mode(1000)
+        ops.chol_mode(old)
+
+
+@gpu
 @pytest.mark.parametrize("m,n", [(192, 32), (6, 6), (36, 32), (17, 32), (12, 4), (5, 1), (1, 3), (300, 48), (64, 64)])
 def test_qr_matches_lapack(m, n):
     """One-workgroup Householder QR against torch.linalg.qr on the CPU (same sign convention)."""
