@@ -589,6 +589,23 @@ class TensorNetwork:
         for n in self.main_nodes:
             self.node_orthonormalize_right(n)
 
+    @staticmethod
+    def _bond_product(Rm, t, first):
+        """The triangular factor of a gauge move into the neighbouring core, over its first axis
+        (sum_j Rm[i,j] t[j,...]) or its last one (sum_j t[...,j] Rm[j,i]): the row GEMM kernel on the
+        device, an einsum for host tensors and other dtypes."""
+        on_dev = t.is_cuda and t.dtype == torch.float64 and Rm.dtype == torch.float64 and Rm.shape[0] <= ops.DENSE_MAX_P \
+            and Rm.shape[1] <= ops.DENSE_MAX_P
+        if first:
+            if on_dev:
+                flat = t.reshape(t.shape[0], -1).contiguous()
+                return ops.gemm_rows(Rm.contiguous(), flat, flat.shape[1]).reshape((Rm.shape[0],) + tuple(t.shape[1:]))
+            return torch.einsum('ij,j...->i...', Rm, t)
+        if on_dev:
+            flat = t.reshape(-1, t.shape[-1]).contiguous()
+            return ops.gemm_rows(flat, Rm.contiguous(), Rm.shape[1]).reshape(tuple(t.shape[:-1]) + (Rm.shape[1],))
+        return torch.einsum('ji,...j->...i', Rm, t)
+
     def node_orthonormalize_left(self, node):
         """core -> Q with orthonormal columns over (left, phys); R moves into the next core."""
         i = self.node_indices[node]
@@ -603,7 +620,7 @@ class TensorNetwork:
         node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))
         nxt = self.main_nodes[i + 1]
         nxt.permute_first(*node.get_connecting_labels(nxt))
-        nxt.tensor = torch.einsum('ij,j...->i...', Rm, nxt.tensor)
+        nxt.tensor = self._bond_product(Rm, nxt.tensor, first=True)
 
     def node_orthonormalize_right(self, node):
         """Mirror image: RQ through a doubly flipped QR; R moves into the previous core."""
@@ -620,7 +637,7 @@ class TensorNetwork:
         node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))
         prev = self.main_nodes[i - 1]
         prev.permute_last(*node.get_connecting_labels(prev))
-        prev.tensor = torch.einsum('ji,...j->...i', Rm, prev.tensor)
+        prev.tensor = self._bond_product(Rm, prev.tensor, first=False)
 
     # ------------------------------------------------------------------ matrix-free sweeps
     def _krylov_setup(self, d, node, y, loss_fn, batch_size, want_loss):
