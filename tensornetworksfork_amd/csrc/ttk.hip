@@ -3185,15 +3185,15 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
         const int c = 16 * u + 4 * t + kq;
         R[r_own][c] = c <= r_own ? acc[0][u][t] : 0.0;
       }
-    __syncthreads();
-    DAG_TRACE(j, 2)
     // The second tile's accumulators wait in dagS meanwhile: the unrolled chains of the factorisation want
-    // every register they can get.
+    // every register they can get (parked in front of the barrier, so that the first sub-panel does not
+    // share the LDS with these stores).
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) dagS[r_own][16 * u + 4 * t + kq] = acc[1][u][t];
-    asm volatile("" ::: "memory");
+    __syncthreads();
+    DAG_TRACE(j, 2)
     const int badcol = dag_factor(j, nb, ctl, tid);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
