@@ -52,7 +52,8 @@ def eager():
 
 fused.iterate(xk, r, pbuf, state, 0)
 fused.iterate(xk, r, pbuf, state, 1)
-t_eager = timed(eager)
+t_eager = timed(eager, reps=1)
+print("state after eager run", state.tolist(), "x norm", xk.norm().item())
 x_eager = xk.clone()
 
 xk, r, pbuf, state = fresh()
@@ -75,5 +76,6 @@ def replay():
         graph.replay()
 
 
-t_graph = timed(replay)
+t_graph = timed(replay, reps=1)
+print("state after replay", state.tolist(), "x norm", xk.norm().item(), "same x", torch.equal(xk, x_eager))
 print(f"{N} fused CG iterations: eager {t_eager * 1e3 / N:.2f} us per iteration, graph replay (blocks of 20) {t_graph * 1e3 / N:.2f} us per iteration")
