@@ -83,27 +83,56 @@ def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):
 def cg_solve_fused(fused, matvec, b, x0, maxiter, rtol, check_every=20):
     """cg_solve on an operator that ops.CGFused takes: every iteration is two launches (the product
     with the direction update in its prologue; the slab reduction with the x / r updates behind it),
-    all scalars stay on the device."""
+    all scalars stay on the device.  On the GPU the iterations run from the shape's ops.CGPlan: blocks of
+    `check_every` iterations replayed from a HIP graph captured once per shape."""
     shape = b.shape
     bf = b.reshape(-1)
-    if x0 is None:
-        xk = torch.zeros_like(bf)
-        r = bf.clone()
+    plan = None
+    if bf.is_cuda and check_every == ops.CGPlan.BLOCK and maxiter > 2:
+        plan = ops.CGPlan.get(*fused.keep)
+        plan.load(*fused.keep)
+        xk, r, pbuf, state = plan.x, plan.r, plan.pbuf, plan.state
+        if x0 is None:
+            xk.zero_()
+            r.copy_(bf)
+        else:
+            xk.copy_(x0.reshape(-1))
+            r.copy_(bf - matvec(xk.reshape(shape)).reshape(-1))
+        pbuf.zero_()
+        bb = ops.dot(bf, bf)
+        state.copy_(torch.stack((torch.zeros_like(bb), ops.dot(r, r), rtol * bb.sqrt(), torch.zeros_like(bb),
+                                 torch.zeros_like(bb))))
     else:
-        xk = x0.reshape(-1).clone()
-        r = bf - matvec(xk.reshape(shape)).reshape(-1)
-    pbuf = torch.zeros(2 * bf.numel(), dtype=b.dtype, device=b.device)
-    bb = ops.dot(bf, bf)
-    state = torch.stack((torch.zeros_like(bb), ops.dot(r, r), rtol * bb.sqrt(), torch.zeros_like(bb), torch.zeros_like(bb)))
-    state = state.contiguous()
-    for it in range(maxiter):
-        fused.iterate(xk, r, pbuf, state, it)
-        if (it + 1) % check_every == 0 and it + 1 < maxiter and state[3].item() != 0.0:
-            break
+        if x0 is None:
+            xk = torch.zeros_like(bf)
+            r = bf.clone()
+        else:
+            xk = x0.reshape(-1).clone()
+            r = bf - matvec(xk.reshape(shape)).reshape(-1)
+        pbuf = torch.zeros(2 * bf.numel(), dtype=b.dtype, device=b.device)
+        bb = ops.dot(bf, bf)
+        state = torch.stack((torch.zeros_like(bb), ops.dot(r, r), rtol * bb.sqrt(), torch.zeros_like(bb), torch.zeros_like(bb)))
+        state = state.contiguous()
+    if plan is None:
+        for it in range(maxiter):
+            fused.iterate(xk, r, pbuf, state, it)
+            if (it + 1) % check_every == 0 and it + 1 < maxiter and state[3].item() != 0.0:
+                break
+    else:
+        # the host reads the stop flag every check_every iterations, as above; between the reads whole blocks
+        it = min(2, maxiter)
+        for k in range(it):
+            plan.fused.iterate(xk, r, pbuf, state, k)
+        while it < maxiter:
+            nxt = min(maxiter, (it // check_every + 1) * check_every)   # up to the next multiple of check_every
+            plan.run(it, nxt - it)
+            it = nxt
+            if it < maxiter and state[3].item() != 0.0:
+                break
     st = state.tolist() + [bb.item()]
     if st[5] == 0.0:
         return torch.zeros_like(b), 0
-    return xk.reshape(shape), (0 if st[3] != 0.0 else maxiter)
+    return xk.reshape(shape).clone() if plan is not None else xk.reshape(shape), (0 if st[3] != 0.0 else maxiter)
 
 
 def minres_solve(matvec, b, x0, maxiter, rtol, check_every=10):
