@@ -280,6 +280,20 @@ int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int
 int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr);
 int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
                         int accumulate, void* ws, int64_t ws_bytes, void* stream);
+
+/* float32 matrix arithmetic for float32 models (image_convolution_lanczos_CIFAR10.py and CIFAR_lanczos_swipe.py
+ * never set a dtype, so the reference contracts in float32: tensor/network.py:101-113, 788-789 on float32
+ * nodes).  Same arguments, layouts and memory types (float64) as the entry points they are named after; the
+ * operands are rounded to float32 when they are staged, products and running sums are float32
+ * (v_mfma_f32_16x16x4_f32, twice the fp64 matrix rate), partial sums over sample slabs and the row dot of
+ * ttk_env_right_dense are added in float64.  Results agree with the _f64 entry points to float32 rounding. */
+int ttk_gemm_rows_mm32(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
+                       int accumulate, void* stream);
+int ttk_env_right_dense_mm32(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
+                             int rr, int accumulate, void* stream);
+int ttk_rhs_feature_mm32(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
+                         int accumulate, void* ws, int64_t ws_bytes, void* stream);
+
 int ttk_dense_scale_f64(const double* A, int D, double* scale, void* stream);
 int ttk_chol_prepare_dense_f64(const double* A, int D, const double* scale, double ridge, const double* b, const double* w,
                                void* chol_ws, void* stream);

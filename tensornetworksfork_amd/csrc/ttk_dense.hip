@@ -14,6 +14,31 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Arithmetic of the matrix products of a kernel.  double: v_mfma_f64_16x16x4_f64.  float: v_mfma_f32_16x16x4_f32
+// for float32 models (image_convolution_lanczos_CIFAR10.py never sets a dtype): operands are rounded to float32
+// when they are staged, products and running sums are float32 at twice the fp64 matrix rate, memory stays
+// float64.  Same operand lane map; result register t of lane l is row 4 (l >> 4) + t instead of (l >> 4) + 4 t.
+// `banks` = LDS banks in elements: a row stride of 16 mod `banks` spreads the four k of an operand read.
+template <typename T>
+struct Mm;
+template <>
+struct Mm<double> {
+  typedef d4 acc_t;
+  static constexpr int banks = 32;
+  static __device__ __forceinline__ int row(int kq, int t) { return kq + 4 * t; }
+  static __device__ __forceinline__ acc_t fma(double a, double b, acc_t c) { return MFMA_F64(a, b, c); }
+};
+template <>
+struct Mm<float> {
+  typedef f4 acc_t;
+  static constexpr int banks = 64;
+  static __device__ __forceinline__ int row(int kq, int t) { return 4 * kq + t; }
+  static __device__ __forceinline__ acc_t fma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
 
 static inline int dense_status() { return hipGetLastError() == hipSuccess ? TTK_OK : TTK_ELAUNCH; }
 
@@ -75,17 +100,29 @@ __global__ __launch_bounds__(256) void conv_feature_kernel(const TI* __restrict_
 // operand read fall on different bank halves) go through LDS in nkc equal K chunks of at most 64.
 // ---------------------------------------------------------------------------------------
 #define GR_NB 24   // prefetch registers per thread for a B block: 64 k x 96 columns / 256 threads
-template <int BMODE, int EPI, int TPL, int LB>
+// LDS row strides in elements.  Bs: 16 mod the bank count.  As ([k][row], written along k, read along row):
+// odd, so that both walks spread over the banks.
+template <typename TC>
+__host__ __device__ constexpr int gemm_rows_bstride(int bw) {
+  return bw + ((16 - bw) & (Mm<TC>::banks - 1));
+}
+template <typename TC>
+__host__ __device__ constexpr int gemm_rows_astride() {
+  return sizeof(TC) == 8 ? 65 : 81;
+}
+template <int BMODE, int EPI, int TPL, int LB, typename TC = double>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                            double* __restrict__ out, int64_t M, int K, int N, int rl,
                                                            int rr, const double* __restrict__ Rv, int accumulate, int kch) {
   extern __shared__ double smem[];
+  typedef Mm<TC> mm;
   constexpr int NT = TPL * LB;
   constexpr int bw = NT * 16;          // columns per pass
-  constexpr int bs = bw + 16 + (bw & 16);   // row stride of Bs, 16 mod 32
+  constexpr int bs = gemm_rows_bstride<TC>(bw);   // row stride of Bs, 16 mod the bank count
+  constexpr int AS = gemm_rows_astride<TC>();     // row stride of As
   const int Kp = (K + 3) & ~3;
-  double* As = smem;                   // [Kp][65]: the whole A tile, staged once
-  double* Bs = smem + Kp * 65;         // [kch][bs]: one K chunk of the B block of a pass
+  TC* As = (TC*)smem;                  // [Kp][AS]: the whole A tile, staged once
+  TC* Bs = As + Kp * AS;               // [kch][bs]: one K chunk of the B block of a pass
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * 64;
   const int mrows = (int)min((int64_t)64, M - m0);
@@ -93,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
   const int nblocks = EPI == 1 ? (rl + LB - 1) / LB : (N + 63) / 64;
   // The B block of step (blk, kc) travels in registers while the previous step is multiplied: loads with
   // clamped sources in one batch, zero selected when the registers go to LDS.
-  double pb[GR_NB];
+  TC pb[GR_NB];
   auto b_src = [&](int idx, int blk, int kc0, int kcn, bool& ok) -> int64_t {
     const int k = idx / bw, c = idx - k * bw;
     const int kk = kc0 + min(k, kcn - 1);
@@ -119,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
 #pragma unroll
     for (int u = 0; u < GR_NB; ++u) {
       bool ok;
-      pb[u] = B[b_src(min(tid + 256 * u, total - 1), blk, kc0, kcn, ok)];
+      pb[u] = (TC)B[b_src(min(tid + 256 * u, total - 1), blk, kc0, kcn, ok)];
     }
   };
   auto store_b = [&](int step) {
@@ -133,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
         bool ok;
         (void)b_src(idx, blk, kc0, kcn, ok);
         const int k = idx / bw, c = idx - k * bw;
-        Bs[k * bs + c] = ok ? pb[u] : 0.0;
+        Bs[k * bs + c] = ok ? pb[u] : (TC)0;
       }
     }
   };
@@ -152,16 +189,16 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (k0 + 256 * u < 64 * K) As[kk_[u] * 65 + rr_[u]] = rr_[u] < mrows ? v[u] : 0.0;
+      if (k0 + 256 * u < 64 * K) As[kk_[u] * AS + rr_[u]] = rr_[u] < mrows ? (TC)v[u] : (TC)0;
   }
-  for (int idx = tid; idx < (Kp - K) * 64; idx += 256) As[(K + idx / 64) * 65 + (idx & 63)] = 0.0;
-  d4 acc[NT];
+  for (int idx = tid; idx < (Kp - K) * 64; idx += 256) As[(K + idx / 64) * AS + (idx & 63)] = (TC)0;
+  typename mm::acc_t acc[NT];
   for (int step = 0; step < nsteps; ++step) {
     const int blk = step / nkc, kc = step - blk * nkc;
     const int kc0 = kc * kch, kcn = min(kch, K - kc0);
     if (kc == 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NT; ++j) acc[j] = typename mm::acc_t{0, 0, 0, 0};
     }
     __syncthreads();   // everybody is done with the previous Bs
     store_b(step);
@@ -169,10 +206,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
     if (step + 1 < nsteps) fetch_b(step + 1);
     const int ksteps = (kcn + 3) >> 2;
     for (int ks = 0; ks < ksteps; ++ks) {
-      const double a = As[(kc0 + ks * 4 + kq) * 65 + wave * 16 + i];
-      const double* brow = Bs + (ks * 4 + kq) * bs + i;
+      const TC a = As[(kc0 + ks * 4 + kq) * AS + wave * 16 + i];
+      const TC* brow = Bs + (ks * 4 + kq) * bs + i;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = MFMA_F64(a, brow[j * 16], acc[j]);
+      for (int j = 0; j < NT; ++j) acc[j] = mm::fma(a, brow[j * 16], acc[j]);
     }
     if (kc + 1 < nkc) continue;
     if (EPI == 0) {
@@ -180,17 +217,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int r = wave * 16 + kq + 4 * t;
+          const int r = wave * 16 + mm::row(kq, t);
           const int col = blk * 64 + j * 16 + i;
           if (r < mrows && col < N) {
             double* o = out + (m0 + r) * N + col;
-            *o = accumulate ? *o + acc[j][t] : acc[j][t];
+            *o = accumulate ? *o + (double)acc[j][t] : (double)acc[j][t];
           }
         }
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int r = wave * 16 + kq + 4 * t;
+        const int r = wave * 16 + mm::row(kq, t);
         const double* rrow = Rv + (m0 + min(r, mrows - 1)) * rr;
         double rvv[TPL];
 #pragma unroll
@@ -199,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const double* __restr
         for (int lsub = 0; lsub < LB; ++lsub) {
           double z = 0.0;
 #pragma unroll
-          for (int j = 0; j < TPL; ++j) z += acc[lsub * TPL + j][t] * rvv[j];
+          for (int j = 0; j < TPL; ++j) z += (double)acc[lsub * TPL + j][t] * rvv[j];
           z += __shfl_xor(z, 8, 16);
           z += __shfl_xor(z, 4, 16);
           z += __shfl_xor(z, 2, 16);
@@ -221,10 +258,238 @@ static int gemm_rows_chunk(int K) {
   const int nkc = (K + 63) / 64;
   return (((K + nkc - 1) / nkc) + 3) & ~3;
 }
+template <typename TC>
 static size_t gemm_rows_lds(int K, int kch, int bw) {
-  return ((size_t)((K + 3) & ~3) * 65 + (size_t)kch * (bw + 16 + (bw & 16))) * sizeof(double);
+  return ((size_t)((K + 3) & ~3) * gemm_rows_astride<TC>() + (size_t)kch * gemm_rows_bstride<TC>(bw)) * sizeof(TC);
 }
 #define GEMM_ROWS_MAX_K 256   // 64 x K A tile + one B chunk stay below 160 KiB
+
+// ---------------------------------------------------------------------------------------
+// Right-environment step of a site with many features, core block resident:
+//   z[s,l] (+)= sum_r (sum_k X[s,k] core[l,k,r]) Rv[s,r]
+// The row-GEMM kernel above restages the B block of every pass in every 64-row workgroup, and that staging
+// (element gathers with their address arithmetic) plus the row dot, not the matrix pipe, is what bounds it.
+// Here a workgroup owns LB consecutive l (NT = TPL LB column tiles) for a range of samples and its core block
+// goes to LDS once.  Its eight waves then work on their own: a wave takes every eighth 16-row tile of the
+// range, copies it (one contiguous block of memory) into a private LDS image [k][row] -- the next tile
+// travelling in registers meanwhile -- multiplies, and does the row dot with Rv; no workgroup barrier after
+// the first, so the dot / staging instructions of one wave run beside the MFMAs of the others.
+// Workgroup -> (sample range, column block): dispatch is round-robin over the 8 XCDs, so blockIdx & 7 picks
+// an eighth of the samples and all column blocks of that eighth run on one XCD, whose L2 then holds its part
+// of X (3.3 MB at 50 000 x 65) for the ncb passes over it.
+// ---------------------------------------------------------------------------------------
+#define ER_AS 17   // row stride of a wave's X tile image [k][16 rows]
+
+// sum over the 16 lanes of a DPP row, left in every lane (rotations by 8, 4, 2, 1 inside the row)
+__device__ __forceinline__ double row16_sum(double z) {
+#define ROW_ROR_ADD(n)                                                                              \
+  {                                                                                                 \
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(z), 0x120 + (n), 0xf, 0xf, false);        \
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(z), 0x120 + (n), 0xf, 0xf, false);        \
+    z += __hiloint2double(hi, lo);                                                                  \
+  }
+  ROW_ROR_ADD(8)
+  ROW_ROR_ADD(4)
+  ROW_ROR_ADD(2)
+  ROW_ROR_ADD(1)
+#undef ROW_ROR_ADD
+  return z;
+}
+__device__ __forceinline__ float row16_sum(float z) {
+#define ROW_ROR_ADD(n) z += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(z), 0x120 + (n), 0xf, 0xf, false));
+  ROW_ROR_ADD(8)
+  ROW_ROR_ADD(4)
+  ROW_ROR_ADD(2)
+  ROW_ROR_ADD(1)
+#undef ROW_ROR_ADD
+  return z;
+}
+
+template <int TPL, int LB, int ER_NA, typename TC>   // ER_NA: X tile elements per lane, 16 rows x K <= 64 ER_NA
+__global__ __launch_bounds__(512, sizeof(TC) == 4 && ER_NA <= 17 ? 4 : 2) void env_right_resident_kernel(
+    const double* __restrict__ X, const double* __restrict__ core, double* __restrict__ out, int64_t S, int K, int rl, int rr,
+    const double* __restrict__ Rv, int accumulate, int ncb, int64_t rows_xcd, int64_t rows_wg) {
+  extern __shared__ double smem[];
+  typedef Mm<TC> mm;
+  constexpr int NT = TPL * LB;
+  constexpr int bw = NT * 16;
+  constexpr int bs = gemm_rows_bstride<TC>(bw);
+  const int Kp = (K + 3) & ~3;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  TC* Bs = (TC*)smem;                          // [Kp][bs]: the core block, staged once
+  TC* Aw = Bs + Kp * bs + wave * Kp * ER_AS;   // [Kp][ER_AS]: this wave's X tile, [k][row]; column 16 is never read
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int cb = q % ncb, split = q / ncb;
+  const int64_t x_end = min(S, (xcd + 1) * rows_xcd);
+  const int64_t m_begin = xcd * rows_xcd + split * rows_wg;
+  const int64_t m_end = min(x_end, m_begin + rows_wg);
+  if (m_begin >= m_end) return;       // the whole workgroup: nothing to wait for yet
+  const int l0 = cb * LB;
+  // element lane + 64 u of a tile is row e / K, column e % K; elements past the tile go to the unused column
+  int adst[ER_NA];
+  {
+    int r = lane / K, c = lane - r * K;
+    const int dr = 64 / K, dc = 64 - dr * K;
+#pragma unroll
+    for (int u = 0; u < ER_NA; ++u) {
+      adst[u] = (lane + 64 * u < 16 * K) ? c * ER_AS + r : 16;
+      c += dc;
+      r += dr;
+      if (c >= K) {
+        c -= K;
+        ++r;
+      }
+    }
+  }
+  // a tile whose 64 ER_NA element reads stay inside X (all but the last few rows) is read without clamping
+  const int64_t plain_end = S - (64 * ER_NA + K - 1) / K;
+  TC pa[ER_NA];
+  auto fetch = [&](int64_t m0) {
+    const double* x0 = X + m0 * K + lane;
+    if (m0 <= plain_end && m0 + 16 <= m_end) {
+#pragma unroll
+      for (int u = 0; u < ER_NA; ++u) pa[u] = (TC)x0[64 * u];
+    } else {
+      const int nvalid = (int)min((int64_t)16, m_end - m0);
+      const int lx = nvalid * K - 1 - lane;     // last valid offset relative to this lane's first element
+#pragma unroll
+      for (int u = 0; u < ER_NA; ++u) pa[u] = (TC)x0[max(min(64 * u, lx), -lane)];
+    }
+  };
+  auto stage = [&](int64_t m0) {
+    if (m0 + 16 <= m_end) {
+#pragma unroll
+      for (int u = 0; u < ER_NA; ++u) Aw[adst[u]] = pa[u];
+    } else {
+      const int lx = (int)(m_end - m0) * K - 1 - lane;
+#pragma unroll
+      for (int u = 0; u < ER_NA; ++u) Aw[adst[u]] = 64 * u <= lx ? pa[u] : (TC)0;
+    }
+  };
+  int64_t m0 = m_begin + wave * 16;
+  if (m0 < m_end) fetch(m0);
+  // the core block: loads in batches of eight, sources clamped, zero selected at the store
+  for (int base = 0; base < Kp * bw; base += 512 * 8) {
+    double v[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = min(base + tid + 512 * u, Kp * bw - 1);
+      const int k = idx / bw, c = idx - k * bw;
+      const int lsub = c / (TPL * 16), r = c - lsub * (TPL * 16), l = l0 + lsub;
+      ok[u] = k < K && r < rr && l < rl;
+      v[u] = core[((int64_t)min(l, rl - 1) * K + min(k, K - 1)) * rr + min(r, rr - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + tid + 512 * u;
+      if (idx < Kp * bw) {
+        const int k = idx / bw, c = idx - k * bw;
+        Bs[k * bs + c] = ok[u] ? (TC)v[u] : (TC)0;
+      }
+    }
+  }
+  for (int e = lane; e < (Kp - K) * 16; e += 64) Aw[(K + e / 16) * ER_AS + (e & 15)] = (TC)0;
+  // columns of Rv a lane multiplies with (past rr: any column, its products are zero)
+  int cj[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) cj[j] = min(j * 16 + i, rr - 1);
+  __syncthreads();                    // the core block is complete; from here on the waves run on their own
+  for (; m0 < m_end; m0 += 128) {
+    const int mrows = (int)min((int64_t)16, m_end - m0);
+    asm volatile("" ::: "memory");    // the products of the previous tile have consumed their operand reads
+    stage(m0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS writes land in order; nobody else reads this image
+    if (m0 + 128 < m_end) fetch(m0 + 128);
+    // the right-environment rows of this tile, wanted after the products
+    TC rvv[4][TPL];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double* rrow = Rv + (m0 + min(mm::row(kq, t), mrows - 1)) * rr;
+#pragma unroll
+      for (int j = 0; j < TPL; ++j) rvv[t][j] = (TC)rrow[cj[j]];
+    }
+    typename mm::acc_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = typename mm::acc_t{0, 0, 0, 0};
+    const TC* a = Aw + kq * ER_AS + i;
+    const TC* b = Bs + kq * bs + i;
+    // two k steps per turn: the operands of one are read while the other is multiplied
+    TC a0 = a[0], b0[NT], a1, b1[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b0[j] = b[j * 16];
+    for (int ks = 0; ks < Kp; ks += 8) {
+      const int k1 = min(ks + 4, Kp - 4), k2 = min(ks + 8, Kp - 4);
+      a1 = a[k1 * ER_AS];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b1[j] = b[k1 * bs + j * 16];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mm::fma(a0, b0[j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a[k2 * ER_AS];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b0[j] = b[k2 * bs + j * 16];
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 4 < Kp) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mm::fma(a1, b1[j], acc[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // row dot with Rv in the arithmetic of the products; lane lsub of a row keeps the sum of l0 + lsub
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      TC zsel = (TC)0;
+#pragma unroll
+      for (int lsub = 0; lsub < LB; ++lsub) {
+        TC z = (TC)0;
+#pragma unroll
+        for (int j = 0; j < TPL; ++j) z += acc[lsub * TPL + j][t] * rvv[t][j];
+        z = row16_sum(z);
+        zsel = (i == lsub) ? z : zsel;
+      }
+      const int r = mm::row(kq, t), l = l0 + i;
+      if (i < LB && r < mrows && l < rl) {
+        double* o = out + (m0 + r) * rl + l;
+        *o = accumulate ? *o + (double)zsel : (double)zsel;
+      }
+    }
+  }
+}
+
+struct EnvResDims {
+  int ncb, nsplit;
+  int64_t rows_xcd, rows_wg;
+  size_t lds;
+};
+// extents of a resident launch for NT column tiles per workgroup; lds = 0 when the site does not fit
+template <typename TC>
+static EnvResDims env_resident_dims(int64_t S, int rl, int K, int lb, int nt) {
+  EnvResDims d;
+  const int Kp = (K + 3) & ~3;
+  d.lds = ((size_t)Kp * gemm_rows_bstride<TC>(nt * 16) + (size_t)8 * Kp * ER_AS) * sizeof(TC);
+  if (K > 96 || K < 4 || d.lds > 150 * 1024) d.lds = 0;
+  d.ncb = (rl + lb - 1) / lb;
+  d.rows_xcd = ((S + 7) / 8 + 63) / 64 * 64;
+  // Sample ranges per XCD: the launch runs in rounds of `slots` workgroups (one per compute unit, two when the
+  // LDS image allows), a workgroup costs its tiles plus about two tiles' worth of staging the core block.
+  const int64_t slots = 256 * (d.lds && d.lds <= 76 * 1024 ? 2 : 1);
+  const int64_t tiles = d.rows_xcd / 64;
+  int64_t best = -1, best_cost = 0;
+  for (int64_t ns = 1; ns <= tiles; ++ns) {
+    const int64_t per = (tiles + ns - 1) / ns, nsplit = (tiles + per - 1) / per;
+    const int64_t rounds = (8 * d.ncb * nsplit + slots - 1) / slots;
+    const int64_t cost = rounds * (per + 2);
+    if (best < 0 || cost < best_cost) {
+      best = per;
+      best_cost = cost;
+    }
+  }
+  d.rows_wg = best * 64;
+  d.nsplit = (int)((tiles + best - 1) / best);
+  return d;
+}
 
 // out[s,c,j] (+)= sum_l L[s,c,l] T[s,l,j]: the output index of the left environment applied to the
 // feature-contracted core (second stage of the left step of a site with many features; also
@@ -403,17 +668,18 @@ __global__ __launch_bounds__(256) void dense_to_chol_kernel(const double* __rest
 // the MFMAs.  Grid = (groups of four column tiles, slabs of samples); every slab writes its own partial result,
 // a second kernel adds the slabs in fixed order.
 // ---------------------------------------------------------------------------------------
-template <int PTC>   // row tiles a wave can hold: p <= 16 PTC
+template <int PTC, typename TC = double>   // PTC: row tiles a wave can hold (p <= 16 PTC); TC: arithmetic of the products
 __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __restrict__ GL, const double* __restrict__ X,
                                                               const double* __restrict__ R, double* __restrict__ partial,
                                                               int64_t S, int rl, int p, int rr, int64_t slab_len) {
   constexpr int CH = PTC == 4 ? 32 : 256 / PTC;   // samples per chunk
-  constexpr int PW = 16 * PTC + 16;       // LDS row of a sample's features: = 16 mod 32 doubles
+  constexpr int PW = 16 * PTC + 16;       // LDS row of a sample's features: = 16 mod 32 (and mod 64 for PTC 4, 8, 16)
   constexpr int XQ = CH * PTC / 16;       // prefetch registers per thread: CH * 16 PTC / 256
   constexpr int BQ = CH / 4;              // 4 waves x CH x 16 / 256
   extern __shared__ double sm[];
-  double* Xs = sm;                        // [CH][PW]
-  double* Bs = sm + CH * PW;              // [4][CH][16]
+  typedef Mm<TC> mm;
+  TC* Xs = (TC*)sm;                       // [CH][PW]
+  TC* Bs = Xs + CH * PW;                  // [4][CH][16]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   const int nrt = (rr + 15) >> 4, pt = (p + 15) >> 4;
   const int64_t s_begin = (int64_t)blockIdx.y * slab_len;
@@ -424,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __res
   const bool active = jt < rl * nrt;
   const int lw = active ? jt / nrt : 0, r0 = active ? (jt - lw * nrt) * 16 : 0;
   // feature columns past p stay zero for the whole launch
-  for (int e = tid; e < CH * PW; e += 256) Xs[e] = 0.0;
+  for (int e = tid; e < CH * PW; e += 256) Xs[e] = (TC)0;
   // staging maps.  X: the chunk is CH * p consecutive doubles; element tid + 256 q goes to row (e / p), column (e % p).
   int xdst[XQ];
   {
@@ -443,13 +709,14 @@ __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __res
   }
   // B: element tid + 256 q = (wave bw, sample k, column j) with j fastest
   const int bj = tid & 15;
-  double px[XQ], pg[BQ], pr[BQ];
+  TC px[XQ];
+  double pg[BQ], pr[BQ];
   auto fetch = [&](int64_t c0) {
     const int nvalid = (int)min((int64_t)CH, s_end - c0);
     const double* x0 = X + c0 * p + tid;
     const int lx = nvalid * p - 1 - tid;
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) px[q] = x0[max(min(256 * q, lx), -tid)];
+    for (int q = 0; q < XQ; ++q) px[q] = (TC)x0[max(min(256 * q, lx), -tid)];
 #pragma unroll
     for (int q = 0; q < BQ; ++q) {
       const int e = tid + 256 * q;
@@ -461,9 +728,9 @@ __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __res
       pr[q] = R[srow * rr + min(rb, rr - 1)];
     }
   };
-  d4 acc[PTC];
+  typename mm::acc_t acc[PTC];
 #pragma unroll
-  for (int u = 0; u < PTC; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int u = 0; u < PTC; ++u) acc[u] = typename mm::acc_t{0, 0, 0, 0};
   if (s_begin < s_end) fetch(s_begin);
   for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
     const int nvalid = (int)min((int64_t)CH, s_end - c0);
@@ -472,27 +739,27 @@ __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __res
       const int lx = nvalid * p - 1 - tid;
 #pragma unroll
       for (int q = 0; q < XQ; ++q)
-        if (xdst[q] >= 0) Xs[xdst[q]] = 256 * q <= lx ? px[q] : 0.0;
+        if (xdst[q] >= 0) Xs[xdst[q]] = 256 * q <= lx ? px[q] : (TC)0;
 #pragma unroll
       for (int q = 0; q < BQ; ++q) {
         const int e = tid + 256 * q;
         const int bw = e / (CH * 16), k = (e >> 4) % CH;
         const int jw = blockIdx.x * 4 + bw;
         const bool ok = k < nvalid && jw < rl * nrt && (jw % nrt) * 16 + bj < rr;
-        Bs[e] = ok ? pg[q] * pr[q] : 0.0;
+        Bs[e] = ok ? (TC)(pg[q] * pr[q]) : (TC)0;
       }
     }
     __syncthreads();
     if (c0 + CH < s_end) fetch(c0 + CH);
     if (active) {
-      const double* bw_ = Bs + wave * CH * 16;
+      const TC* bw_ = Bs + wave * CH * 16;
 #pragma unroll 2
       for (int ks = 0; ks < CH / 4; ++ks) {
-        const double bf = bw_[(ks * 4 + kq) * 16 + li];
-        const double* xrow = Xs + (ks * 4 + kq) * PW + li;
+        const TC bf = bw_[(ks * 4 + kq) * 16 + li];
+        const TC* xrow = Xs + (ks * 4 + kq) * PW + li;
 #pragma unroll
         for (int u = 0; u < PTC; ++u)
-          if (u < pt) acc[u] = MFMA_F64(xrow[16 * u], bf, acc[u]);
+          if (u < pt) acc[u] = mm::fma(xrow[16 * u], bf, acc[u]);
       }
     }
   }
@@ -501,8 +768,8 @@ __global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __res
     for (int u = 0; u < PTC; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int pp = 16 * u + kq + 4 * t;
-        if (u < pt && pp < p) dst[((int64_t)lw * p + pp) * rr + r0 + li] = acc[u][t];
+        const int pp = 16 * u + mm::row(kq, t);
+        if (u < pt && pp < p) dst[((int64_t)lw * p + pp) * rr + r0 + li] = (double)acc[u][t];
       }
   }
 }
@@ -549,18 +816,150 @@ static int conv_feature_rows(int px, int nab) {
 }
 
 // dynamic LDS above 64 KiB (long K) has to be allowed once per kernel
+template <typename TC>
 static bool gemm_rows_allow_lds() {
   static int state = 0;   // 0 not tried, 1 ok, -1 failed
   if (state == 0) {
-    const void* fns[] = {(const void*)gemm_rows_kernel<0, 0, 4, 1>, (const void*)gemm_rows_kernel<1, 0, 4, 1>,
-                         (const void*)gemm_rows_kernel<2, 0, 4, 1>, (const void*)gemm_rows_kernel<1, 1, 1, 6>,
-                         (const void*)gemm_rows_kernel<1, 1, 2, 3>, (const void*)gemm_rows_kernel<1, 1, 3, 2>,
-                         (const void*)gemm_rows_kernel<1, 1, 4, 1>};
+    const void* fns[] = {(const void*)gemm_rows_kernel<0, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 0, 4, 1, TC>,
+                         (const void*)gemm_rows_kernel<2, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 1, 1, 6, TC>,
+                         (const void*)gemm_rows_kernel<1, 1, 2, 3, TC>, (const void*)gemm_rows_kernel<1, 1, 3, 2, TC>,
+                         (const void*)gemm_rows_kernel<1, 1, 4, 1, TC>};
     state = 1;
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) state = -1;
   }
   return state == 1;
+}
+
+template <typename TC>
+static int gemm_rows_launch(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
+                            int accumulate, void* stream) {
+  if (!A || !B || !T || M < 1 || K < 1 || N < 1 || bmode < 0 || bmode > 2) return TTK_EINVAL;
+  if (bmode == 1 && (rl < 1 || rr < 1 || (int64_t)rl * rr != N)) return TTK_EINVAL;
+  const dim3 grid((unsigned)((M + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  const int kch = gemm_rows_chunk(K);
+  if (K > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  const size_t lds = gemm_rows_lds<TC>(K, kch, 64);
+  if (!gemm_rows_allow_lds<TC>()) return TTK_ELAUNCH;
+  const double* none = nullptr;
+  if (bmode == 0)
+    hipLaunchKernelGGL((gemm_rows_kernel<0, 0, 4, 1, TC>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate,
+                       kch);
+  else if (bmode == 1)
+    hipLaunchKernelGGL((gemm_rows_kernel<1, 0, 4, 1, TC>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate,
+                       kch);
+  else
+    hipLaunchKernelGGL((gemm_rows_kernel<2, 0, 4, 1, TC>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate,
+                       kch);
+  return dense_status();
+}
+
+template <typename TC>
+static int env_right_dense_launch(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
+                                  int rr, int accumulate, void* stream) {
+  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  if (!gemm_rows_allow_lds<TC>()) return TTK_ELAUNCH;
+  const dim3 grid((unsigned)((S + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  const int kch = gemm_rows_chunk(p);
+  const int N = rl * rr;
+  {
+    // core block resident (the usual case: p <= 96): one launch over (XCD, column block, sample range)
+    const int tpl = (rr + 15) / 16, lb = tpl == 1 ? 6 : (tpl == 2 ? 3 : (tpl == 3 ? 2 : 1));
+    const EnvResDims d = env_resident_dims<TC>(S, rl, p, lb, tpl * lb);
+    if (d.lds) {
+      const dim3 rgrid((unsigned)(8 * d.ncb * d.nsplit));
+#define ER_LAUNCH(TPL_, LB_, NA_)                                                                                        \
+  {                                                                                                                      \
+    static bool allowed = false;   /* more than 64 KiB of dynamic LDS needs the attribute once per kernel */            \
+    if (!allowed && hipFuncSetAttribute((const void*)env_right_resident_kernel<TPL_, LB_, NA_, TC>,                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)           \
+      return TTK_ELAUNCH;                                                                                                \
+    allowed = true;                                                                                                      \
+    hipLaunchKernelGGL((env_right_resident_kernel<TPL_, LB_, NA_, TC>), rgrid, dim3(512), d.lds, st, X, core, out, S, p, \
+                       rl, rr, R, accumulate, d.ncb, d.rows_xcd, d.rows_wg);                                             \
+  }
+#define ER_LAUNCH_NA(TPL_, LB_)       \
+  if (p <= 68)                        \
+    ER_LAUNCH(TPL_, LB_, 17)          \
+  else                                \
+    ER_LAUNCH(TPL_, LB_, 24)
+      switch (tpl) {
+        case 1:
+          ER_LAUNCH_NA(1, 6)
+          break;
+        case 2:
+          ER_LAUNCH_NA(2, 3)
+          break;
+        case 3:
+          ER_LAUNCH_NA(3, 2)
+          break;
+        default:
+          ER_LAUNCH_NA(4, 1)
+          break;
+      }
+#undef ER_LAUNCH_NA
+#undef ER_LAUNCH
+      return dense_status();
+    }
+  }
+  // (tiles per l) x (l per pass): six 16-wide tiles per pass where the bond allows it
+  switch ((rr + 15) / 16) {
+    case 1:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 1, 6, TC>), grid, dim3(256), gemm_rows_lds<TC>(p, kch, 96), st, X, core, out, S, p,
+                         N, rl, rr, R, accumulate, kch);
+      break;
+    case 2:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 2, 3, TC>), grid, dim3(256), gemm_rows_lds<TC>(p, kch, 96), st, X, core, out, S, p,
+                         N, rl, rr, R, accumulate, kch);
+      break;
+    case 3:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 3, 2, TC>), grid, dim3(256), gemm_rows_lds<TC>(p, kch, 96), st, X, core, out, S, p,
+                         N, rl, rr, R, accumulate, kch);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 4, 1, TC>), grid, dim3(256), gemm_rows_lds<TC>(p, kch, 64), st, X, core, out, S, p,
+                         N, rl, rr, R, accumulate, kch);
+      break;
+  }
+  return dense_status();
+}
+
+template <typename TC>
+static int rhs_feature_launch(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
+                              int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+  if (!GL || !X || !R || !b || !ws || S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
+  if (ws_bytes < ttk_rhs_feature_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
+  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)d.ngroups, (unsigned)d.nslabs);
+  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
+  const size_t lds = ((size_t)ch * (16 * d.ptc + 16) + (size_t)4 * ch * 16) * sizeof(TC);
+  static bool allowed = false;   // more than 64 KiB of dynamic LDS needs the attribute once per process
+  if (!allowed) {
+    if (hipFuncSetAttribute((const void*)rhs_feature_kernel<4, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)rhs_feature_kernel<8, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)rhs_feature_kernel<16, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
+            hipSuccess)
+      return TTK_ELAUNCH;
+    allowed = true;
+  }
+  double* partial = (double*)ws;
+  if (d.ptc == 4)
+    hipLaunchKernelGGL((rhs_feature_kernel<4, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  else if (d.ptc == 8)
+    hipLaunchKernelGGL((rhs_feature_kernel<8, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  else
+    hipLaunchKernelGGL((rhs_feature_kernel<16, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+  int rc = dense_status();
+  if (rc != TTK_OK) return rc;
+  const int64_t D = (int64_t)rl * p * rr;
+  hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)partial,
+                     d.nslabs, D, b, accumulate);
+  return dense_status();
 }
 
 extern "C" {
@@ -587,52 +986,22 @@ int ttk_conv_feature_f32(const float* X, const double* F, double* G, int64_t row
 
 int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
                       int accumulate, void* stream) {
-  if (!A || !B || !T || M < 1 || K < 1 || N < 1 || bmode < 0 || bmode > 2) return TTK_EINVAL;
-  if (bmode == 1 && (rl < 1 || rr < 1 || (int64_t)rl * rr != N)) return TTK_EINVAL;
-  const dim3 grid((unsigned)((M + 63) / 64));
-  hipStream_t st = (hipStream_t)stream;
-  const int kch = gemm_rows_chunk(K);
-  if (K > GEMM_ROWS_MAX_K) return TTK_EINVAL;
-  const size_t lds = gemm_rows_lds(K, kch, 64);
-  if (!gemm_rows_allow_lds()) return TTK_ELAUNCH;
-  const double* none = nullptr;
-  if (bmode == 0)
-    hipLaunchKernelGGL((gemm_rows_kernel<0, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
-  else if (bmode == 1)
-    hipLaunchKernelGGL((gemm_rows_kernel<1, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
-  else
-    hipLaunchKernelGGL((gemm_rows_kernel<2, 0, 4, 1>), grid, dim3(256), lds, st, A, B, T, M, K, N, rl, rr, none, accumulate, kch);
-  return dense_status();
+  return gemm_rows_launch<double>(A, B, T, M, K, N, bmode, rl, rr, accumulate, stream);
+}
+
+int ttk_gemm_rows_mm32(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
+                       int accumulate, void* stream) {
+  return gemm_rows_launch<float>(A, B, T, M, K, N, bmode, rl, rr, accumulate, stream);
 }
 
 int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
                             int rr, int accumulate, void* stream) {
-  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
-  if (!gemm_rows_allow_lds()) return TTK_ELAUNCH;
-  const dim3 grid((unsigned)((S + 63) / 64));
-  hipStream_t st = (hipStream_t)stream;
-  const int kch = gemm_rows_chunk(p);
-  const int N = rl * rr;
-  // (tiles per l) x (l per pass): six 16-wide tiles per pass where the bond allows it
-  switch ((rr + 15) / 16) {
-    case 1:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 1, 6>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
-                         rr, R, accumulate, kch);
-      break;
-    case 2:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 2, 3>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
-                         rr, R, accumulate, kch);
-      break;
-    case 3:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 3, 2>), grid, dim3(256), gemm_rows_lds(p, kch, 96), st, X, core, out, S, p, N, rl,
-                         rr, R, accumulate, kch);
-      break;
-    default:
-      hipLaunchKernelGGL((gemm_rows_kernel<1, 1, 4, 1>), grid, dim3(256), gemm_rows_lds(p, kch, 64), st, X, core, out, S, p, N, rl,
-                         rr, R, accumulate, kch);
-      break;
-  }
-  return dense_status();
+  return env_right_dense_launch<double>(R, X, core, out, S, rl, p, rr, accumulate, stream);
+}
+
+int ttk_env_right_dense_mm32(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
+                             int rr, int accumulate, void* stream) {
+  return env_right_dense_launch<float>(R, X, core, out, S, rl, p, rr, accumulate, stream);
 }
 
 int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
@@ -689,37 +1058,12 @@ int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr) {
 
 int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
                         int accumulate, void* ws, int64_t ws_bytes, void* stream) {
-  if (!GL || !X || !R || !b || !ws || S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
-  if (ws_bytes < ttk_rhs_feature_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
-  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)d.ngroups, (unsigned)d.nslabs);
-  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
-  const size_t lds = ((size_t)ch * (16 * d.ptc + 16) + (size_t)4 * ch * 16) * sizeof(double);
-  static bool allowed = false;   // more than 64 KiB of dynamic LDS needs the attribute once per process
-  if (!allowed) {
-    if (hipFuncSetAttribute((const void*)rhs_feature_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)rhs_feature_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)rhs_feature_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess)
-      return TTK_ELAUNCH;
-    allowed = true;
-  }
-  double* partial = (double*)ws;
-  if (d.ptc == 4)
-    hipLaunchKernelGGL(rhs_feature_kernel<4>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
-  else if (d.ptc == 8)
-    hipLaunchKernelGGL(rhs_feature_kernel<8>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
-  else
-    hipLaunchKernelGGL(rhs_feature_kernel<16>, grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
-  int rc = dense_status();
-  if (rc != TTK_OK) return rc;
-  const int64_t D = (int64_t)rl * p * rr;
-  hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)partial,
-                     d.nslabs, D, b, accumulate);
-  return dense_status();
+  return rhs_feature_launch<double>(GL, X, R, b, S, rl, p, rr, accumulate, ws, ws_bytes, stream);
+}
+
+int ttk_rhs_feature_mm32(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
+                         int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+  return rhs_feature_launch<float>(GL, X, R, b, S, rl, p, rr, accumulate, ws, ws_bytes, stream);
 }
 
 int ttk_dense_scale_f64(const double* A, int D, double* scale, void* stream) {

@@ -51,8 +51,9 @@ DENSE_MIN_P = 16    # from this many features on a site contracts its features f
 DENSE_MAX_P = 256   # ... up to what the row GEMM keeps in LDS (beyond: the streaming Khatri-Rao kernels)
 
 
-def env_step_right(R, X, core, out=None):
-    """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl); with `out` given the result is added to it."""
+def env_step_right(R, X, core, out=None, mm32=False):
+    """R (S,rr), X (S,p), core (rl,p,rr) -> (S,rl); with `out` given the result is added to it.  `mm32`: float32
+    matrix arithmetic on the many-feature route (float32 models)."""
     S, rr = R.shape
     rl, p = core.shape[0], core.shape[1]
     acc = out is not None
@@ -62,12 +63,13 @@ def env_step_right(R, X, core, out=None):
         return out
     if DENSE_MIN_P <= p <= DENSE_MAX_P and rr == 1 and not acc:
         # the last site: out[s,l] = (X . core[:, :, 0]^T)[s,l] R[s,0], a plain row GEMM and a row scaling
-        T = gemm_rows(X, core.reshape(rl, p), rl, bmode=2)
+        T = gemm_rows(X, core.reshape(rl, p), rl, bmode=2, mm32=mm32)
         return kr_rows(T.unsqueeze(1), R, R.new_ones((S, 1))).reshape(S, rl)
     if DENSE_MIN_P <= p <= DENSE_MAX_P and rr <= 64:
-        rc = _lib.lib().ttk_env_right_dense_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
-                                                _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
-        _lib.check(rc, "ttk_env_right_dense_f64")
+        fn = _lib.lib().ttk_env_right_dense_mm32 if mm32 else _lib.lib().ttk_env_right_dense_f64
+        rc = fn(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)), _chk(out, "out", (S, rl)), S, rl, p, rr,
+                int(acc), _stream(R))
+        _lib.check(rc, "ttk_env_right_dense")
         return out
     rc = _lib.lib().ttk_env_step_right_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
                                            _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
@@ -503,9 +505,10 @@ def gl(g, L):
 _rhsf_ws = {}
 
 
-def rhs_feature(L, X, R, g, out=None):
+def rhs_feature(L, X, R, g, out=None, mm32=False):
     """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r] for a site with many features
-    (DENSE_MIN_P <= p <= DENSE_MAX_P), features first; with `out` given the result is added to it."""
+    (DENSE_MIN_P <= p <= DENSE_MAX_P), features first; with `out` given the result is added to it.
+    `mm32`: float32 matrix arithmetic (float32 models)."""
     S, C, rl = L.shape
     p, rr = X.shape[1], R.shape[1]
     GL = gl(g, L)
@@ -520,9 +523,10 @@ def rhs_feature(L, X, R, g, out=None):
         _rhsf_ws[key] = ws
     acc = out is not None
     b = out if acc else torch.empty((rl, p, rr), dtype=F64, device=L.device)
-    rc = _lib.lib().ttk_rhs_feature_f64(GL.data_ptr(), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(b, "b", (rl, p, rr)),
-                                        S, rl, p, rr, int(acc), ws.data_ptr(), nbytes, _stream(L))
-    _lib.check(rc, "ttk_rhs_feature_f64")
+    fn = _lib.lib().ttk_rhs_feature_mm32 if mm32 else _lib.lib().ttk_rhs_feature_f64
+    rc = fn(GL.data_ptr(), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(b, "b", (rl, p, rr)), S, rl, p, rr, int(acc),
+            ws.data_ptr(), nbytes, _stream(L))
+    _lib.check(rc, "ttk_rhs_feature")
     return b
 
 
@@ -541,16 +545,17 @@ def conv_feature(X, Fc):
     return G
 
 
-def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None):
-    """T (M, N) (+)= A (M, K) B; bmode 0: B (K, N); 1: B = core (rl, K, rr), columns (l, r); 2: B (N, K) transposed."""
+def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None, mm32=False):
+    """T (M, N) (+)= A (M, K) B; bmode 0: B (K, N); 1: B = core (rl, K, rr), columns (l, r); 2: B (N, K) transposed.
+    `mm32`: float32 matrix arithmetic (float32 models)."""
     M, K = A.shape
     acc = out is not None
     T = out if acc else torch.empty((M, N), dtype=F64, device=A.device)
     if M == 0:
         return T
-    rc = _lib.lib().ttk_gemm_rows_f64(_chk(A, "A"), _chk(B, "B"), _chk(T, "T", (M, N)), M, K, int(N), int(bmode), int(rl),
-                                      int(rr), int(acc), _stream(A))
-    _lib.check(rc, "ttk_gemm_rows_f64")
+    fn = _lib.lib().ttk_gemm_rows_mm32 if mm32 else _lib.lib().ttk_gemm_rows_f64
+    rc = fn(_chk(A, "A"), _chk(B, "B"), _chk(T, "T", (M, N)), M, K, int(N), int(bmode), int(rl), int(rr), int(acc), _stream(A))
+    _lib.check(rc, "ttk_gemm_rows")
     return T
 
 
@@ -568,12 +573,12 @@ def lcontract(L, T, out=None):
     return o
 
 
-def env_step_left_dense(E, X, core, out=None):
+def env_step_left_dense(E, X, core, out=None, mm32=False):
     """env_step_left for a site with many features: T = X . core (one GEMM shared by the C outputs),
     then the left environment's output index."""
     S, C, rl = E.shape
     p, rr = core.shape[1], core.shape[2]
-    T = gemm_rows(X, core, rl * rr, bmode=1, rl=rl, rr=rr)
+    T = gemm_rows(X, core, rl * rr, bmode=1, rl=rl, rr=rr, mm32=mm32)
     return lcontract(E, T.reshape(S, rl, rr), out=out)
 
 

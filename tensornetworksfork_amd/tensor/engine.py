@@ -154,6 +154,7 @@ class LocalProblem:
         self.terms = terms
         self.J = J
         self._Jt = None
+        self.mm32 = False               # float32 matrix arithmetic on the many-feature route (set by the engine)
 
     # -- first order
     def _jt(self):
@@ -175,7 +176,8 @@ class LocalProblem:
         for (L, X, R) in self.terms:
             if _rhs_features_first(L.shape[2], X.shape[1], R.shape[1]):
                 # many features and a wide output: the GEMM over the samples with the features as rows
-                out = ops.rhs_feature(L, X, R, g) if out is None else ops.rhs_feature(L, X, R, g, out=out)
+                out = ops.rhs_feature(L, X, R, g, mm32=self.mm32) if out is None else \
+                    ops.rhs_feature(L, X, R, g, out=out, mm32=self.mm32)
             elif not ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
                 # a sample row too wide for the right-hand-side kernel's LDS chunk: features last,
                 # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L, as one transposed product over the samples
@@ -202,7 +204,7 @@ class LocalProblem:
             if TWO_STAGE_MIN_P <= X.shape[1] <= TWO_STAGE_MAX_P:
                 # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (one GEMM shared by the
                 # C outputs of a sample, never stored), then the two environments: C*p/(C+p) times fewer FLOPs
-                z = ops.env_step_right(R, X, v.contiguous())                             # (S, rl)
+                z = ops.env_step_right(R, X, v.contiguous(), mm32=self.mm32)             # (S, rl)
                 u = ops.predict(L, z) if u is None else ops.predict(L, z, out=u)         # (S, C)
                 continue
             key = id(R)                  # terms that share R share one environment-step buffer
@@ -241,7 +243,9 @@ class LocalProblem:
         if self.J is not None:
             return LocalProblem(hi - lo, self.C, self.shape, self.core, self.back, J=self.J[lo:hi])
         terms = [(L[lo:hi], X[lo:hi], R[lo:hi]) for (L, X, R) in self.terms]
-        return LocalProblem(hi - lo, self.C, self.shape, self.core, self.back, terms=terms)
+        part = LocalProblem(hi - lo, self.C, self.shape, self.core, self.back, terms=terms)
+        part.mm32 = self.mm32
+        return part
 
     # -- Gram
     def single_term(self):
@@ -577,6 +581,12 @@ class ChainEngine(EngineBase):
             return self._back(node, col.order, col.sizes, t)
         return self._back(node, col.f_order, col.f_sizes, t)
 
+    @property
+    def mm32(self):
+        """A float32 model (the reference then contracts in float32: image_convolution_lanczos_CIFAR10.py sets no
+        dtype) runs the matrix products of its many-feature sites in float32; everything else stays float64."""
+        return self.net.main_nodes[0].tensor.dtype == torch.float32
+
     # ------------------------------------------------------------------ data sets
     def site_list(self, x):
         cols = self.require()
@@ -639,7 +649,7 @@ class ChainEngine(EngineBase):
                 Fc = self.canonF(k)                                   # (ca, u, dd, cb)
                 u, dd = col.inner
                 Bm = Fc.permute(2, 0, 3, 1).reshape(dd, col.ca * col.cb * u).contiguous()
-                flat = ops.gemm_rows(X, Bm, col.ca * col.cb * u)
+                flat = ops.gemm_rows(X, Bm, col.ca * col.cb * u, mm32=self.mm32)
                 d.G[k] = flat.reshape(X.shape[0], col.ca, col.cb, u).permute(1, 2, 0, 3).contiguous()
         return d.G[k]
 
@@ -665,8 +675,8 @@ class ChainEngine(EngineBase):
             o = None
             for a in range(ca):
                 if two_stage:
-                    o = ops.env_step_left_dense(Lk[a], G[a, b], core) if o is None else \
-                        ops.env_step_left_dense(Lk[a], G[a, b], core, out=o)
+                    o = ops.env_step_left_dense(Lk[a], G[a, b], core, mm32=self.mm32) if o is None else \
+                        ops.env_step_left_dense(Lk[a], G[a, b], core, out=o, mm32=self.mm32)
                 else:
                     o = ops.env_step_left(Lk[a], G[a, b], core) if o is None else \
                         ops.env_step_left(Lk[a], G[a, b], core, out=o)
@@ -686,8 +696,8 @@ class ChainEngine(EngineBase):
                 for a in range(ca):
                     o = None
                     for b in range(cb):   # (a site with many features contracts them first inside the op)
-                        o = ops.env_step_right(Rn[b], G[a, b], core) if o is None else \
-                            ops.env_step_right(Rn[b], G[a, b], core, out=o)
+                        o = ops.env_step_right(Rn[b], G[a, b], core, mm32=self.mm32) if o is None else \
+                            ops.env_step_right(Rn[b], G[a, b], core, out=o, mm32=self.mm32)
                     outs.append(o)
                 d.R[k] = torch.stack(outs) if ca > 1 else outs[0].unsqueeze(0)
         return d.R[k]
@@ -740,7 +750,9 @@ class ChainEngine(EngineBase):
                 d.pairs_done = True
                 self.prefetch_pairs([self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"])
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
-            return LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
+            prob = LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
+            prob.mm32 = self.mm32
+            return prob
         # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (a row GEMM, then the left environment's output index)
         #   conv filter    J[s,c,a,x,b]   = sum_patch M_ab[s,c,patch] X[s,patch,x]
         #   operator node  J[s,c,a,u,d,b] = M_ab[s,c,u] X[s,d]   (one Khatri-Rao term when a = b = 1)
@@ -750,7 +762,7 @@ class ChainEngine(EngineBase):
         A2 = core.reshape(col.rl * col.p, col.rr)
 
         def M(a, b):
-            U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2).reshape(S, col.rl, col.p)
+            U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
             return ops.lcontract(L[a], U)                  # (S, C, p)
 
         if col.kind == "op" and ca == 1 and cb == 1:

@@ -13,7 +13,7 @@ def env_step_left(E, X, core, out=None):
     return r if out is None else out.add_(r)
 
 
-def env_step_right(R, X, core, out=None):
+def env_step_right(R, X, core, out=None, mm32=False):
     r = torch.einsum('sr,sp,lpr->sl', R, X, core)
     return r if out is None else out.add_(r)
 
@@ -88,7 +88,7 @@ def rhs(L, X, R, g, out=None):
     return r if out is None else out.add_(r)
 
 
-def rhs_feature(L, X, R, g, out=None):
+def rhs_feature(L, X, R, g, out=None, mm32=False):
     return rhs(L, X, R, g, out=out)
 
 
@@ -137,7 +137,7 @@ def conv_feature(X, Fc):
     return torch.einsum('spx,axb->absp', X.to(F64), Fc).contiguous()
 
 
-def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None):
+def gemm_rows(A, B, N, bmode=0, rl=0, rr=0, out=None, mm32=False):
     if bmode == 0:
         T = A @ B
     elif bmode == 1:
@@ -152,7 +152,7 @@ def lcontract(L, T, out=None):
     return r if out is None else out.add_(r)
 
 
-def env_step_left_dense(E, X, core, out=None):
+def env_step_left_dense(E, X, core, out=None, mm32=False):
     return env_step_left(E, X, core, out=out)
 
 

@@ -251,6 +251,50 @@ def test_rhs_feature_matches_oracle(S, C, rl, p, rr):
     assert torch.equal(ops.rhs_feature(L.to(dev), X.to(dev), R.to(dev), g.to(dev)), b)   # fixed summation order
 
 
+def _small_ints(shape, seed, hi=4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-hi, hi + 1, shape, generator=g).to(torch.float64)
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", [(300, 1, 4, 16, 4), (1000, 3, 24, 50, 24), (777, 9, 48, 65, 48), (129, 2, 1, 17, 5),
+                                         (500, 1, 7, 130, 9), (260, 2, 3, 256, 2), (64, 1, 5, 33, 1), (200, 2, 6, 40, 64)])
+def test_float32_matrix_arithmetic_of_many_feature_sites(S, C, rl, p, rr):
+    """The float32 instantiations (v_mfma_f32_16x16x4_f32) of the row GEMM, the dense right-environment step and
+    the features-first right-hand side: (1) on small integers every float32 product and sum is exact, so the
+    result must EQUAL the oracle's einsum -- this pins the operand / result lane maps and every ragged edge;
+    (2) on random data the error against the fp64 einsum stays at float32 rounding (1e-5 of the largest entry:
+    sums of up to 65 x 64 products per entry, 1 000 samples per slab)."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    for exact in (True, False):
+        mk = (lambda sh, sd: _small_ints(sh, sd)) if exact else (lambda sh, sd: _rand(sh, sd))
+        L, X, R, g = mk((S, C, rl), 91), mk((S, p), 92), mk((S, rr), 93), mk((S, C), 94)
+        core = mk((rl, p, rr), 95)
+        Ld, Xd, Rd, gd, cd = (t.to(dev) for t in (L, X, R, g, core))
+
+        def check(got, ref):
+            if exact:
+                assert torch.equal(got.cpu(), ref)
+            else:
+                assert (got.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+        ref_b = torch.einsum('sc,scl,sp,sr->lpr', g, L, X, R)
+        check(ops.rhs_feature(Ld, Xd, Rd, gd, mm32=True), ref_b)
+        check(ops.rhs_feature(Ld, Xd, Rd, gd, out=ops.rhs_feature(Ld, Xd, Rd, gd, mm32=True), mm32=True), 2 * ref_b)
+        ref_z = torch.einsum('sr,sp,lpr->sl', R, X, core)
+        z = ops.env_step_right(Rd, Xd, cd, mm32=True)
+        check(z, ref_z)
+        check(ops.env_step_right(Rd, Xd, cd, out=z.clone(), mm32=True), 2 * ref_z)
+        ref_t = torch.einsum('sk,lkr->slr', X, core).reshape(S, rl * rr)
+        check(ops.gemm_rows(Xd, cd, rl * rr, bmode=1, rl=rl, rr=rr, mm32=True), ref_t)
+        Bm = mk((p, 37), 96)
+        check(ops.gemm_rows(Xd, Bm.to(dev), 37, bmode=0, mm32=True), X @ Bm)
+        check(ops.gemm_rows(Xd, Bm.T.contiguous().to(dev), 37, bmode=2, mm32=True), X @ Bm)
+        ref_l = torch.einsum('scl,sp,lpr->scr', L, X, core)
+        check(ops.env_step_left_dense(Ld, Xd, cd, mm32=True), ref_l)
+
+
 @gpu
 @pytest.mark.parametrize("n", [40, 64, 130, 512, 1000, 2304])
 def test_cholesky_single_launch_matches_multi_launch(n):
