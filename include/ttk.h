@@ -273,7 +273,8 @@ int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
 int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream);
 
-/* Right-hand side / J^T u of a site with many features (16 <= p <= 256; a conv column has one per patch):
+/* Right-hand side / J^T u of a site with many features (16 <= p <= 256, rr <= 128, p + rr <= 280: two chunk
+ * images in LDS; other extents return TTK_EINVAL and belong to ttk_rhs_f64; a conv column has one feature per patch):
  *   b (rl,p,rr) (+)= sum_s GL[s,l] X[s,pp] R[s,r],   GL (S,rl) = the gradient-weighted left factor (ttk_gl_f64)
  * i.e. the einsum of get_A_b / get_b (tensor/network.py:205-217, 258-291) after the conv feature contraction
  * (tensor/layers.py:839-872), features first.  ws: ttk_rhs_feature_ws_bytes(S, rl, p, rr) bytes of slab partials. */

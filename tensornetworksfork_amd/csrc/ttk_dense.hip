@@ -658,119 +658,165 @@ __global__ __launch_bounds__(256) void dense_to_chol_kernel(const double* __rest
 // rows of X a workgroup of conv_feature_kernel stages (its LDS image stays below 60 KiB)
 
 // ---------------------------------------------------------------------------------------
-// Right-hand side / J^T u of a site with many features (16 <= p <= 256), features first:
+// Right-hand side / J^T u of a site with many features (16 <= p <= 256, rr <= 128), features first:
 //   b[l, pp, r] = sum_s X[s, pp] * (GL[s, l] R[s, r]),      GL[s, l] = sum_c g[s, c] L[s, c, l]
 // as a GEMM over the samples with rows pp and columns (l, r): the feature rows of a chunk of samples are
 // staged once per workgroup and serve all its output columns, whereas the three-factor kernel of the few-feature
 // sites would stream every slab of samples once per 96 output columns (33 times at 48 x 65 x 48).
-// A wave owns one 16-column tile (l, r0 .. r0+15) and all ceil(p / 16) row tiles; its right operand
-// GL[s, l] R[s, r0 + j] is formed while the chunk is staged, so the inner loop is one LDS read per operand and
-// the MFMAs.  Grid = (groups of four column tiles, slabs of samples); every slab writes its own partial result,
-// a second kernel adds the slabs in fixed order.
+// A wave owns NCW consecutive 16-column tiles (l, r-tile) and all PTC row tiles: PTC x NCW accumulator tiles, so
+// an operand read from LDS feeds NCW (features) or PTC (right factor) MFMAs; the eight waves of a workgroup
+// share the chunk images of X, R and GL (32 samples, double-buffered: one barrier per chunk, the next chunk
+// travelling in registers meanwhile) and form GL[s,l] R[s,r] on the fly.  Grid = (groups of 8 NCW column tiles,
+// slabs of samples); every slab writes its own partial result, a second kernel adds the slabs in fixed order.
 // ---------------------------------------------------------------------------------------
-template <int PTC, typename TC = double>   // PTC: row tiles a wave can hold (p <= 16 PTC); TC: arithmetic of the products
-__global__ __launch_bounds__(256, 2) void rhs_feature_kernel(const double* __restrict__ GL, const double* __restrict__ X,
-                                                              const double* __restrict__ R, double* __restrict__ partial,
-                                                              int64_t S, int rl, int p, int rr, int64_t slab_len) {
-  constexpr int CH = PTC == 4 ? 32 : 256 / PTC;   // samples per chunk
-  constexpr int PW = 16 * PTC + 16;       // LDS row of a sample's features: = 16 mod 32 (and mod 64 for PTC 4, 8, 16)
-  constexpr int XQ = CH * PTC / 16;       // prefetch registers per thread: CH * 16 PTC / 256
-  constexpr int BQ = CH / 4;              // 4 waves x CH x 16 / 256
-  extern __shared__ double sm[];
+#define RF_CH 32   // samples per chunk
+template <int PTC, int NCW, typename TC>   // p <= 16 PTC
+__global__ __launch_bounds__(512, sizeof(TC) == 4 && PTC <= 8 ? 4 : 2) void rhs_feature_kernel(
+    const double* __restrict__ GL, const double* __restrict__ X, const double* __restrict__ R, double* __restrict__ partial,
+    int64_t S, int rl, int p, int rr, int64_t slab_len, int gw) {
   typedef Mm<TC> mm;
-  TC* Xs = (TC*)sm;                       // [CH][PW]
-  TC* Bs = Xs + CH * PW;                  // [4][CH][16]
+  constexpr int CH = RF_CH;
+  constexpr int XQ = PTC;                 // X elements per thread and chunk: CH * 16 PTC / 512
+  constexpr int RQ = 8;                   // R elements per thread and chunk: CH * 128 / 512
+  extern __shared__ double sm[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   const int nrt = (rr + 15) >> 4, pt = (p + 15) >> 4;
+  // A chunk image is the three blocks as they lie in memory: Xs [CH][p] | Rs [CH][rr] | Gs [CH][gw].  Tile columns
+  // past p (past rr) read on into the next row or block: finite values that only reach rows pp >= p (columns
+  // r >= rr) of the accumulators, which are never stored.
+  const int bufsz = CH * (p + rr + gw);
+  TC* img = (TC*)sm;
   const int64_t s_begin = (int64_t)blockIdx.y * slab_len;
   const int64_t s_end = min(S, s_begin + slab_len);
   const int64_t D = (int64_t)rl * p * rr;
   double* dst = partial + (int64_t)blockIdx.y * D;
-  const int jt = blockIdx.x * 4 + wave;
-  const bool active = jt < rl * nrt;
-  const int lw = active ? jt / nrt : 0, r0 = active ? (jt - lw * nrt) * 16 : 0;
-  // feature columns past p stay zero for the whole launch
-  for (int e = tid; e < CH * PW; e += 256) Xs[e] = (TC)0;
-  // staging maps.  X: the chunk is CH * p consecutive doubles; element tid + 256 q goes to row (e / p), column (e % p).
-  int xdst[XQ];
-  {
-    int r = tid / p, c = tid - r * p;
-    const int dr = 256 / p, dc = 256 - dr * p;
+  const int ntiles = rl * nrt;
+  const int jt_wg = blockIdx.x * (8 * NCW);         // first column tile of the workgroup
+  const int l_lo = jt_wg / nrt;                     // Gs holds GL[:, l_lo .. l_lo + gw)
+  // this wave's column tiles: LDS offsets of their GL and R entries (tiles past the end repeat the last one)
+  int goff[NCW], roff[NCW];
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-      xdst[q] = (tid + 256 * q < CH * p) ? r * PW + c : -1;
-      c += dc;
-      r += dr;
-      if (c >= p) {
-        c -= p;
-        ++r;
-      }
-    }
+  for (int c = 0; c < NCW; ++c) {
+    const int jt = min(jt_wg + wave * NCW + c, ntiles - 1);
+    const int l = jt / nrt;
+    goff[c] = l - l_lo;
+    roff[c] = (jt - l * nrt) * 16 + li;
   }
-  // B: element tid + 256 q = (wave bw, sample k, column j) with j fastest
-  const int bj = tid & 15;
-  TC px[XQ];
-  double pg[BQ], pr[BQ];
+  const int rq = (CH * rr + 511) / 512;             // live R registers
+  const int gq = (CH * gw + 511) / 512;             // live GL registers (at most 2: gw <= 32)
+  TC px[XQ], pr[RQ], pg[2];
   auto fetch = [&](int64_t c0) {
     const int nvalid = (int)min((int64_t)CH, s_end - c0);
     const double* x0 = X + c0 * p + tid;
     const int lx = nvalid * p - 1 - tid;
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) px[q] = (TC)x0[max(min(256 * q, lx), -tid)];
+    for (int q = 0; q < XQ; ++q) px[q] = (TC)x0[max(min(512 * q, lx), -tid)];
+    const double* r0 = R + c0 * rr + tid;
+    const int lr = nvalid * rr - 1 - tid;
 #pragma unroll
-    for (int q = 0; q < BQ; ++q) {
-      const int e = tid + 256 * q;
-      const int bw = e / (CH * 16), k = (e >> 4) % CH;
-      const int jw = blockIdx.x * 4 + bw;
-      const int l = min(jw / nrt, rl - 1), rb = (jw % nrt) * 16 + bj;
-      const int64_t srow = c0 + min(k, nvalid - 1);
-      pg[q] = GL[srow * rl + l];
-      pr[q] = R[srow * rr + min(rb, rr - 1)];
-    }
-  };
-  typename mm::acc_t acc[PTC];
+    for (int q = 0; q < RQ; ++q)
+      if (q < rq) pr[q] = (TC)r0[max(min(512 * q, lr), -tid)];
 #pragma unroll
-  for (int u = 0; u < PTC; ++u) acc[u] = typename mm::acc_t{0, 0, 0, 0};
-  if (s_begin < s_end) fetch(s_begin);
-  for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
-    const int nvalid = (int)min((int64_t)CH, s_end - c0);
-    __syncthreads();   // every wave is done with the previous chunk (and, the first time, the zero fill is complete)
-    {
-      const int lx = nvalid * p - 1 - tid;
-#pragma unroll
-      for (int q = 0; q < XQ; ++q)
-        if (xdst[q] >= 0) Xs[xdst[q]] = 256 * q <= lx ? px[q] : (TC)0;
-#pragma unroll
-      for (int q = 0; q < BQ; ++q) {
-        const int e = tid + 256 * q;
-        const int bw = e / (CH * 16), k = (e >> 4) % CH;
-        const int jw = blockIdx.x * 4 + bw;
-        const bool ok = k < nvalid && jw < rl * nrt && (jw % nrt) * 16 + bj < rr;
-        Bs[e] = ok ? (TC)(pg[q] * pr[q]) : (TC)0;
+    for (int q = 0; q < 2; ++q)
+      if (q < gq) {
+        const int e = min(tid + 512 * q, CH * gw - 1);
+        const int k = e / gw, j = e - k * gw;
+        pg[q] = (TC)GL[(c0 + min(k, nvalid - 1)) * rl + min(l_lo + j, rl - 1)];
       }
-    }
-    __syncthreads();
-    if (c0 + CH < s_end) fetch(c0 + CH);
-    if (active) {
-      const TC* bw_ = Bs + wave * CH * 16;
+  };
+  auto stage = [&](int64_t c0, int buf) {
+    const int nvalid = (int)min((int64_t)CH, s_end - c0);
+    TC* b = img + buf * bufsz;
+    const int lx = nvalid * p - 1 - tid;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q)
+      if (tid + 512 * q < CH * p) b[tid + 512 * q] = 512 * q <= lx ? px[q] : (TC)0;     // samples past the slab: zero features
+#pragma unroll
+    for (int q = 0; q < RQ; ++q)
+      if (q < rq && tid + 512 * q < CH * rr) b[CH * p + tid + 512 * q] = pr[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < gq && tid + 512 * q < CH * gw) b[CH * (p + rr) + tid + 512 * q] = pg[q];
+  };
+  typename mm::acc_t acc[PTC][NCW];
+#pragma unroll
+  for (int u = 0; u < PTC; ++u)
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) acc[u][c] = typename mm::acc_t{0, 0, 0, 0};
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    stage(s_begin, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t c0 = s_begin; c0 < s_end; c0 += CH, buf ^= 1) {
+    const bool more = c0 + CH < s_end;
+    if (more) fetch(c0 + CH);
+    const TC* xs = img + buf * bufsz + kq * p + li;
+    const TC* rs = img + buf * bufsz + CH * p + kq * rr;
+    const TC* gs = img + buf * bufsz + CH * (p + rr) + kq * gw;
+    // Row tiles past p are read like the others (the image has room behind it) and skipped at the products.
+    TC a0[PTC], g0[NCW], r0[NCW], a1[PTC], g1[NCW], r1[NCW];
+    auto ld = [&](int ks, TC* a, TC* g, TC* r) {
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) {
+        g[c] = gs[ks * 4 * gw + goff[c]];
+        r[c] = rs[ks * 4 * rr + roff[c]];
+      }
+#pragma unroll
+      for (int u = 0; u < PTC; ++u) a[u] = xs[ks * 4 * p + 16 * u];
+    };
+    auto mma = [&](const TC* a, const TC* g, const TC* r) {
+      TC bf[NCW];
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) bf[c] = g[c] * r[c];
+#pragma unroll
+      for (int u = 0; u < PTC; ++u)
+        if (u < pt) {
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[u][c] = mm::fma(a[u], bf[c], acc[u][c]);
+        }
+    };
+    if constexpr (sizeof(TC) == 8 && PTC <= 5) {
+      // two waves per SIMD and registers to spare: read ahead explicitly
+      ld(0, a0, g0, r0);
+#pragma unroll
+      for (int ks = 0; ks < CH / 4; ks += 2) {
+        ld(ks + 1, a1, g1, r1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, g0, r0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < CH / 4) ld(ks + 2, a0, g0, r0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, g1, r1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // (float32: four waves per SIMD cover the operand reads of each other)
 #pragma unroll 2
       for (int ks = 0; ks < CH / 4; ++ks) {
-        const TC bf = bw_[(ks * 4 + kq) * 16 + li];
-        const TC* xrow = Xs + (ks * 4 + kq) * PW + li;
-#pragma unroll
-        for (int u = 0; u < PTC; ++u)
-          if (u < pt) acc[u] = mm::fma(xrow[16 * u], bf, acc[u]);
+        ld(ks, a0, g0, r0);
+        mma(a0, g0, r0);
       }
     }
+    if (more) stage(c0 + CH, buf ^ 1);
+    __syncthreads();   // the next chunk is complete, and everybody is done with this one
   }
-  if (active && r0 + li < rr) {
 #pragma unroll
-    for (int u = 0; u < PTC; ++u)
+  for (int c = 0; c < NCW; ++c) {
+    const int jt = jt_wg + wave * NCW + c;
+    if (jt < ntiles) {
+      const int l = jt / nrt, r = (jt - l * nrt) * 16 + li;
+      if (r < rr) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int pp = 16 * u + mm::row(kq, t);
-        if (u < pt && pp < p) dst[((int64_t)lw * p + pp) * rr + r0 + li] = (double)acc[u][t];
+        for (int u = 0; u < PTC; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int pp = 16 * u + mm::row(kq, t);
+            if (u < pt && pp < p) dst[((int64_t)l * p + pp) * rr + r] = (double)acc[u][c][t];
+          }
       }
+    }
   }
 }
 
@@ -790,22 +836,37 @@ __global__ __launch_bounds__(256) void dense_reduce_slabs_kernel(const double* _
 }
 
 struct RhsFeatDims {
-  int ptc, ngroups, nslabs;
+  int ptc, ncw, ngroups, nslabs, gw;
   int64_t slab_len;
+  size_t lds;
 };
+template <typename TC>
 static RhsFeatDims rhs_feature_dims(int64_t S, int rl, int p, int rr) {
   RhsFeatDims d;
-  d.ptc = p <= 64 ? 4 : (p <= 128 ? 8 : 16);
-  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
-  d.ngroups = (rl * ((rr + 15) / 16) + 3) / 4;
-  int ns = 1024 / d.ngroups;
-  const int64_t maxs = (S + 4 * ch - 1) / (4 * ch);   // at least four chunks per slab
-  if (ns > maxs) ns = (int)maxs;
-  if (ns > 64) ns = 64;
+  d.ptc = p <= 64 ? 4 : (p <= 80 ? 5 : (p <= 128 ? 8 : 16));
+  d.ncw = d.ptc <= 5 ? 3 : (d.ptc == 8 ? 2 : 1);
+  const int nrt = (rr + 15) / 16;
+  const int per = 8 * d.ncw;                              // column tiles per workgroup
+  d.ngroups = (rl * nrt + per - 1) / per;
+  d.gw = (per - 1) / nrt + 2;                             // l values a run of `per` tiles can touch
+  if (d.gw > rl) d.gw = rl;
+  if (d.gw < 1) d.gw = 1;
+  d.lds = ((size_t)2 * RF_CH * (p + rr + d.gw) + 16 * d.ptc) * sizeof(TC);   // + room for reads of row tiles past p
+  // one round of workgroups (two per compute unit when the float32 images leave room), at least four chunks a slab
+  const int wgs = 256 * (sizeof(TC) == 4 && d.lds <= 78 * 1024 && d.ptc * d.ncw <= 15 ? 2 : 1);
+  int64_t ns = wgs / d.ngroups;
+  const int64_t maxs = (S + 4 * RF_CH - 1) / (4 * RF_CH);
+  if (ns > maxs) ns = maxs;
+  if (ns > 128) ns = 128;
   if (ns < 1) ns = 1;
-  d.slab_len = ((S + ns - 1) / ns + ch - 1) / ch * ch;
+  d.slab_len = ((S + ns - 1) / ns + RF_CH - 1) / RF_CH * RF_CH;
   d.nslabs = (int)((S + d.slab_len - 1) / d.slab_len);
   return d;
+}
+
+// extents the features-first right-hand side takes: the two fp64 chunk images must fit the LDS
+static bool rhs_feature_fits(int64_t S, int rl, int p, int rr) {
+  return S >= 1 && rl >= 1 && p >= 16 && p <= 256 && rr >= 1 && rr <= 128 && p + rr <= 280;
 }
 
 static int conv_feature_rows(int px, int nab) {
@@ -929,31 +990,31 @@ static int env_right_dense_launch(const double* R, const double* X, const double
 template <typename TC>
 static int rhs_feature_launch(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
                               int accumulate, void* ws, int64_t ws_bytes, void* stream) {
-  if (!GL || !X || !R || !b || !ws || S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
+  if (!GL || !X || !R || !b || !ws || !rhs_feature_fits(S, rl, p, rr)) return TTK_EINVAL;
   if (ws_bytes < ttk_rhs_feature_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
-  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
+  const RhsFeatDims d = rhs_feature_dims<TC>(S, rl, p, rr);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)d.ngroups, (unsigned)d.nslabs);
-  const int ch = d.ptc == 4 ? 32 : 256 / d.ptc;
-  const size_t lds = ((size_t)ch * (16 * d.ptc + 16) + (size_t)4 * ch * 16) * sizeof(TC);
-  static bool allowed = false;   // more than 64 KiB of dynamic LDS needs the attribute once per process
-  if (!allowed) {
-    if (hipFuncSetAttribute((const void*)rhs_feature_kernel<4, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)rhs_feature_kernel<8, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)rhs_feature_kernel<16, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) !=
-            hipSuccess)
-      return TTK_ELAUNCH;
-    allowed = true;
-  }
   double* partial = (double*)ws;
+#define RF_LAUNCH(PTC_, NCW_)                                                                                          \
+  {                                                                                                                    \
+    static bool allowed = false;   /* more than 64 KiB of dynamic LDS needs the attribute once per kernel */          \
+    if (!allowed && hipFuncSetAttribute((const void*)rhs_feature_kernel<PTC_, NCW_, TC>,                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)         \
+      return TTK_ELAUNCH;                                                                                              \
+    allowed = true;                                                                                                    \
+    hipLaunchKernelGGL((rhs_feature_kernel<PTC_, NCW_, TC>), grid, dim3(512), d.lds, st, GL, X, R, partial, S, rl, p, \
+                       rr, d.slab_len, d.gw);                                                                          \
+  }
   if (d.ptc == 4)
-    hipLaunchKernelGGL((rhs_feature_kernel<4, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+    RF_LAUNCH(4, 3)
+  else if (d.ptc == 5)
+    RF_LAUNCH(5, 3)
   else if (d.ptc == 8)
-    hipLaunchKernelGGL((rhs_feature_kernel<8, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+    RF_LAUNCH(8, 2)
   else
-    hipLaunchKernelGGL((rhs_feature_kernel<16, TC>), grid, dim3(256), lds, st, GL, X, R, partial, S, rl, p, rr, d.slab_len);
+    RF_LAUNCH(16, 1)
+#undef RF_LAUNCH
   int rc = dense_status();
   if (rc != TTK_OK) return rc;
   const int64_t D = (int64_t)rl * p * rr;
@@ -1051,9 +1112,10 @@ int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int
 }
 
 int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr) {
-  if (S < 1 || rl < 1 || p < 16 || p > 256 || rr < 1) return TTK_EINVAL;
-  const RhsFeatDims d = rhs_feature_dims(S, rl, p, rr);
-  return (int64_t)d.nslabs * rl * p * rr * (int64_t)sizeof(double);
+  if (!rhs_feature_fits(S, rl, p, rr)) return TTK_EINVAL;
+  // the float32 launch may use more (never fewer than half as many) slabs: size for the larger of the two
+  const int ns = max(rhs_feature_dims<double>(S, rl, p, rr).nslabs, rhs_feature_dims<float>(S, rl, p, rr).nslabs);
+  return (int64_t)ns * rl * p * rr * (int64_t)sizeof(double);
 }
 
 int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,

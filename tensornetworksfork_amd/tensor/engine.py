@@ -126,14 +126,15 @@ def _ones_col(S, device):
 def _rhs_features_first(rl, p, rr):
     """Whether J^T u of a Khatri-Rao term goes to the features-first kernel.  The three-factor kernel streams
     every slab of samples once per 4 x 96 output columns ("passes"); the features-first one stages a chunk once
-    for all its columns but needs enough 16-column tiles (l, r-tile) to fill the device.  Measured (S = 50 000,
-    C = 9): 48 x 65 x 48 (33 passes) 1.4 -> 0.5 ms; 24 x 50 x 24 (7 passes) and the edge sites (one bond of 1)
-    are faster on the three-factor kernel."""
-    if not TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P:
+    for all its columns but pays a fixed cost (the GL product, the slab sum) that small sites do not earn back.
+    Measured (S = 50 000 .. 54 000, C = 9 .. 10; features-first vs three-factor, us): 48 x 65 x 48 (33 passes)
+    407 / 1558, 24 x 50 x 24 (7) 149 / 249, 1 x 65 x 48 (17) 143 / 694, 1 x 50 x 24 (7) 128 / 213,
+    16 x 40 x 16 (4) 109 / 117, 32 x 16 x 32 (3) 105 / 98, 12 x 30 x 12 (2) 50 / 41, 48 x 65 x 1 (1) 180 / 90."""
+    if not TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P or rr > 128 or p + rr > 280:
         return False
     blocks = (((rl + 15) // 16 + 1) // 2) * (((p * rr + 15) // 16 + 2) // 3)
     passes = (blocks + 3) // 4
-    return passes >= 12 and rl * ((rr + 15) // 16) >= 24
+    return passes >= 6
 
 
 class LocalProblem:

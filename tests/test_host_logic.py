@@ -192,11 +192,15 @@ def test_pairwise_contraction_device():
 
 def test_rhs_route_for_many_feature_sites():
     """Which right-hand-side kernel a Khatri-Rao term goes to: the features-first one only where the site has
-    many features, a wide output and enough 16-column tiles (the shapes the choice was measured on)."""
+    many features and an output wide enough to earn back its fixed cost (the shapes the choice was measured on),
+    and only inside the extents its chunk images fit."""
     from tensornetworksfork_amd.tensor.engine import _rhs_features_first
     assert _rhs_features_first(48, 65, 48)          # CIFAR carriage
-    assert not _rhs_features_first(24, 50, 24)      # MNIST carriage: few passes of the three-factor kernel
-    assert not _rhs_features_first(1, 65, 48)       # edge site: three column tiles would not fill the device
-    assert not _rhs_features_first(48, 65, 1)
+    assert _rhs_features_first(24, 50, 24)          # MNIST carriage
+    assert _rhs_features_first(1, 65, 48)           # edge site with a wide right bond
+    assert not _rhs_features_first(48, 65, 1)       # right edge: one pass of the three-factor kernel
+    assert not _rhs_features_first(12, 30, 12)
     assert not _rhs_features_first(32, 6, 32)       # few features: never
     assert not _rhs_features_first(48, 300, 48)     # beyond the kernel's feature limit
+    assert not _rhs_features_first(48, 200, 100)    # two chunk images would not fit the LDS
+    assert not _rhs_features_first(4, 64, 200)      # bond beyond the staged width

@@ -22,7 +22,8 @@ def timed(fn, n=20):
 
 
 for (S, C, rl, p, rr) in [(50000, 10, 48, 65, 48), (54000, 9, 24, 50, 24), (50000, 10, 48, 65, 1), (50000, 10, 16, 40, 16),
-                          (50000, 10, 64, 65, 64)]:
+                          (50000, 10, 64, 65, 64), (50000, 10, 1, 65, 48), (54000, 9, 1, 50, 24), (54000, 9, 24, 50, 1),
+                          (54000, 9, 8, 20, 8), (54000, 9, 32, 16, 32), (20000, 3, 12, 30, 12)]:
     g = torch.Generator().manual_seed(1)
     R = torch.rand((S, rr), generator=g, dtype=torch.float64).to(dev)
     X = torch.rand((S, p), generator=g, dtype=torch.float64).to(dev)
@@ -33,7 +34,10 @@ for (S, C, rl, p, rr) in [(50000, 10, 48, 65, 48), (54000, 9, 24, 50, 24), (5000
     for mm32 in (False, True):
         t = timed(lambda: ops.env_step_right(R, X, core, mm32=mm32))
         line = f"S={S} {rl}x{p}x{rr} {'f32' if mm32 else 'f64'}: env_right {t:7.1f} us {fl / t * 1e-6:6.1f} TF/s"
-        if p >= 16 and rr > 1:
+        if p >= 16:
             t2 = timed(lambda: ops.rhs_feature(L, X, R, gr, mm32=mm32))
             line += f" | rhs_feature {t2:7.1f} us {fl / t2 * 1e-6:6.1f} TF/s"
+            if not mm32 and ops.rhs_supported(S, C, rl, p, rr):
+                t3 = timed(lambda: ops.rhs(L, X, R, gr))
+                line += f" | three-factor rhs {t3:7.1f} us"
         print(line, flush=True)
