@@ -2623,8 +2623,11 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
 // timestamps (100 MHz) of the diagonal chain, 16 per block column, behind the table of compute units
 #define DAG_TRACE(col, k) \
   if (tid == 0) ((long long*)(ctl + (size_t)(nb + 2) * DAG_SLOT + DAG_CU_WORDS))[(col) * 16 + (k)] = wall_clock64();
+#define DAG_TRACE_VAL(col, k, v) \
+  ((long long*)(ctl + (size_t)(nb + 2) * DAG_SLOT + DAG_CU_WORDS))[(col) * 16 + (k)] = (long long)(v);
 #else
 #define DAG_TRACE(col, k)
+#define DAG_TRACE_VAL(col, k, v)
 #endif
 #define DAG_SPIN_LIMIT (1u << 21)     // polls before a waiting lane gives up (seconds)
 typedef unsigned int dag_u4 __attribute__((ext_vector_type(4)));
@@ -2932,6 +2935,59 @@ __device__ __forceinline__ void dag_dinv16(int s0, int lane) {
   }
 }
 
+// The second tile's last term in quarters.  C2 = A_{j+1,j} - sum_k L_{j+1,k} L_{jk}^T misses its term k = j-1
+// until a worker has published L_{j+1,j-1}, which happens while the diagonal tile is being factorised.  C2 waits
+// in dagS (plain row-major) meanwhile, and the term is applied to that copy in four quarters of 16 values of k,
+// always in the same order and with the same assignment of k to lanes, whoever applies them: waves 2 and 3
+// beside the factorisation and the inversion when the flag is already up (NG = 2: 32 rows per wave), all four
+// waves after the inversion for whatever is left (NG = 1: 16 rows per wave).  The bits of the result therefore
+// do not depend on when the worker was done.  Operands come straight from memory in MFMA operand layout:
+// lane (li, kq) takes k = 8 grp + 2 kq, + 1 of a group of eight by one 16-byte sc1 load.
+__shared__ unsigned dag_late;   // quarters released: 0, or 4 once the worker's tile has been seen
+template <int NG>
+__device__ __forceinline__ void dag_late_quarter(__amdgpu_buffer_rsrc_t rs, int ld, int j, int qtr, int row0,
+                                                 int lane) {
+  const int li = lane & 15, kq = lane >> 4;
+  const unsigned col = (unsigned)(((j - 1) * CHB + qtr * 16 + 2 * kq) * 8);
+  double pa[4][2][2], qa[NG][2][2];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      dag_load2(rs, (unsigned)((int64_t)(j * CHB + 16 * u + li) * ld * 8) + col + grp * 64, pa[u][grp][0],
+                pa[u][grp][1]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      dag_load2(rs, (unsigned)((int64_t)((j + 1) * CHB + row0 + 16 * g + li) * ld * 8) + col + grp * 64,
+                qa[g][grp][0], qa[g][grp][1]);
+  }
+  d4 acc[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[g][u][t] = dagS[row0 + 16 * g + li][16 * u + 4 * t + kq];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[g][u] = MFMA_F64(-pa[u][grp][e], qa[g][grp][e], acc[g][u]);
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dagS[row0 + 16 * g + li][16 * u + 4 * t + kq] = acc[g][u][t];
+}
+// One lane: releases the four quarters once the worker's tile is out (a single look, no wait).
+__device__ __forceinline__ void dag_late_release(unsigned* rowready, int j) {
+  if (dag_late == 0u && dag_poll(rowready + (size_t)(j + 1) * DAG_SLOT) >= (unsigned)j) dag_late = 4u;
+}
+
 // All four waves: W = L^-1 of the factorised tile in dagR, by block distance from the diagonal:
 // W_ab = -Dinv_a * sum_{m=b}^{a-1} L_am W_mb, W_bb = Dinv_b.  Block W_ab, a > b (and the sum before it), is
 // kept untransposed in the UPPER block (b, a) of dagR: W[16a + r][16b + c] = dagR[16b + r][16a + c]; the
@@ -2967,7 +3023,9 @@ __device__ __forceinline__ void dag_inv_fin(int li, int kq) {
 }
 // The inverse of the last diagonal block is not there yet when this starts (the factorisation has just
 // finished its last sub-panel): wave 1 forms it in the first phase, beside the blocks that do not need it.
-__device__ __forceinline__ void dag_invert(int tid) {
+// Waves 2 and 3 have little to do in the first phase: with lq >= 0 they first apply quarter lq of the second
+// tile's last term (dag_late_quarter).
+__device__ __forceinline__ void dag_invert(int tid, int lq, __amdgpu_buffer_rsrc_t rs, int ld, int j) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
   if (wave == 0) {
     dag_inv_sum<1, 0>(li, kq);
@@ -2975,9 +3033,11 @@ __device__ __forceinline__ void dag_invert(int tid) {
   } else if (wave == 1) {
     dag_dinv16(48, lane);
   } else if (wave == 2) {
+    if (lq >= 0) dag_late_quarter<2>(rs, ld, j, lq, 0, lane);
     dag_inv_sum<2, 1>(li, kq);
     dag_inv_fin<2, 1>(li, kq);
   } else {
+    if (lq >= 0) dag_late_quarter<2>(rs, ld, j, lq, 32, lane);
     dag_inv_sum<3, 2>(li, kq);
   }
   __syncthreads();
@@ -3003,40 +3063,57 @@ __device__ __forceinline__ void dag_invert(int tid) {
 // dag_invert) and waves 2, 3 update the tiles
 // further right; the tile column the next sub-panel needs is updated by all waves in between.  Returns 0, or
 // 1 + the column of the first non-positive pivot (meaningful in wave 0).
-__device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, int tid) {
+__device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, __amdgpu_buffer_rsrc_t rs, int ld,
+                                          unsigned* rowready, int& late_done, int tid) {
+  (void)nb; (void)ctl;   // named by the trace macro only
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kq = lane >> 4;
   chol_lds_t R = dagR;
-  (void)j; (void)nb; (void)ctl;
-    int badcol = 0;
+  int badcol = 0;
+  int avail = 0, done = 0;   // quarters of the second tile's last term: released / applied (the same in every wave)
 #pragma unroll 1
-    for (int ph = 0; ph < 4; ++ph) {
-      const int c0 = ph * 16;
-      if (wave == 0) {
-        const int bc = dag_f16(c0, lane);
-        if (bc && !badcol) badcol = bc;
-      } else if (wave == 1) {
-        if (ph >= 1) dag_dinv16(c0 - 16, lane);
-      } else {
-        int n = wave - 2;
-        if (ph >= 1) {
-          for (int tj = ph + 1; tj < 4; ++tj)
-            for (int ti = tj; ti < 4; ++ti, ++n)
-              if (!(n & 1)) chol_tile_update(R, R, R, ti, tj, c0 - 16, li, kq);
+  for (int ph = 0; ph < 4; ++ph) {
+    const int c0 = ph * 16;
+    if (wave == 0) {
+      const int bc = dag_f16(c0, lane);
+      if (bc && !badcol) badcol = bc;
+    } else if (wave == 1) {
+      // the only writer of dag_late, and only here: the other waves read it between the two barriers below
+      if (j > 0 && lane == 0) {
+        const unsigned before = dag_late;
+        dag_late_release(rowready, j);
+        if (ph == 0) {   // nothing else to do in this phase: two more looks
+          dag_late_release(rowready, j);
+          dag_late_release(rowready, j);
         }
+        if (before == 0u && dag_late != 0u) { DAG_TRACE_VAL(j, 10, wall_clock64()) }
       }
-      __syncthreads();
-      if (ph == 0) { DAG_TRACE(j, 12) }
-      if (ph == 1) { DAG_TRACE(j, 14) }
-      if (ph == 2) { DAG_TRACE(j, 15) }
-      if (ph == 3) break;
-      {
-        int n = wave;
-        for (int ti = ph + 1; ti < 4; ++ti, ++n)
-          if (!(n & 3)) chol_tile_update(R, R, R, ti, ph + 1, c0, li, kq);
+      if (ph >= 1) dag_dinv16(c0 - 16, lane);
+    } else {
+      int n = wave - 2;
+      if (ph >= 1) {
+        for (int tj = ph + 1; tj < 4; ++tj)
+          for (int ti = tj; ti < 4; ++ti, ++n)
+            if (!(n & 1)) chol_tile_update(R, R, R, ti, tj, c0 - 16, li, kq);
       }
-      __syncthreads();
-      if (ph == 0) { DAG_TRACE(j, 13) }
+      if (avail > done) dag_late_quarter<2>(rs, ld, j, done, 32 * (wave - 2), lane);
     }
+    if (avail > done) ++done;
+    __syncthreads();
+    avail = (int)dag_late;
+    if (ph == 0) { DAG_TRACE(j, 12) }
+    if (ph == 1) { DAG_TRACE(j, 14) }
+    if (ph == 2) { DAG_TRACE(j, 15) }
+    if (ph == 3) break;
+    {
+      int n = wave;
+      for (int ti = ph + 1; ti < 4; ++ti, ++n)
+        if (!(n & 3)) chol_tile_update(R, R, R, ti, ph + 1, c0, li, kq);
+    }
+    __syncthreads();
+    if (ph == 0) { DAG_TRACE(j, 13) }
+  }
+  // one more quarter beside the first phase of the inversion (see dag_invert)
+  late_done = done | (avail > done ? 0x100 : 0);
   return badcol;
 }
 
@@ -3192,27 +3269,32 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) dagS[r_own][16 * u + 4 * t + kq] = acc[1][u][t];
+    if (tid == 0) dag_late = 0u;
     __syncthreads();
     DAG_TRACE(j, 2)
-    const int badcol = dag_factor(j, nb, ctl, tid);
+    int late = 0;
+    const int badcol = dag_factor(j, nb, ctl, rs, ld, rowready, late, tid);
+    if (wave == 0 && badcol && lane == 0) atomicCAS(info, 0, j * CHB + badcol);
+    DAG_TRACE(j, 3)
+    int late_done = late & 0xff;
+    dag_invert(tid, (late & 0x100) ? late_done : -1, rs, ld, j);
+    if (late & 0x100) ++late_done;
+    DAG_TRACE(j, 4)
+    if (tid == 0) { DAG_TRACE_VAL(j, 11, late_done) }
+    if (j > 0 && late_done < 4) {   // what is left of the second tile's last term (all of it if the worker was late)
+      if (dag_late == 0u && !dag_wait(rowready, ctl, j + 1, j + 1, j + 1, (unsigned)j, tid)) {
+        if (tid == 0) atomicCAS(info, 0, -1);
+        return;
+      }
+#pragma unroll 1
+      for (int q = late_done; q < 4; ++q) dag_late_quarter<1>(rs, ld, j, q, 16 * wave, lane);
+      __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[1][u][t] = dagS[r_own][16 * u + 4 * t + kq];
     __syncthreads();   // dagS is about to be used for staging again
-    if (wave == 0 && badcol && lane == 0) atomicCAS(info, 0, j * CHB + badcol);
-    DAG_TRACE(j, 3)
-    dag_invert(tid);
-    DAG_TRACE(j, 4)
-    if (j > 0) {   // the second tile's last term (a prefetch across the inversion only gets spilled)
-      if (!dag_wait(rowready, ctl, j + 1, j + 1, j + 1, (unsigned)j, tid)) {
-        if (tid == 0) atomicCAS(info, 0, -1);
-        return;
-      }
-      DagBlock blk2;
-      dag_block_fetch(blk2, rs, ld, j, j + 1, j - 1, tid);
-      dag_block_apply<2>(blk2, acc[1], (double (*)[CHB + 1]) & dagS[32][0], tid);
-    }
     DAG_TRACE(j, 5)
     // L_{j+1,j} = C W^T first: it is what the next diagonal task waits for.  W_j follows; the workers that wait
     // for it feed the diagonal chain only a whole factorisation later.

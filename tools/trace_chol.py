@@ -45,3 +45,12 @@ start = tr[:, 0].numpy(); a8 = tr[:, 8].numpy(); a9 = tr[:, 9].numpy(); a1 = tr[
 t0 = start[0]
 for jj in list(range(1, nb, 6)) + [nb - 1]:
     print(f"  col {jj:2d}: start {start[jj]-t0:8.1f}  bulk acc done {a8[jj]-t0:8.1f}  L(j,j-1) seen {a9[jj]-t0:8.1f}  acc done {a1[jj]-t0:8.1f}   (prev L out {lout[jj-1]-t0:8.1f})")
+
+# second tile's last term: quarters applied beside the factorisation / inversion, and when the worker's tile was seen
+raw = cw.view(torch.int64)[off // 8: off // 8 + nb * 16].reshape(nb, 16).cpu()
+early = raw[1:, 11].numpy()
+print("  quarters applied early, histogram 0..4:", [int((early == k).sum()) for k in range(5)])
+seen = raw[1:, 10].double().numpy() / 100.0
+ok = raw[1:, 10].numpy() != 0
+f0 = tr[1:, 2].numpy()
+print(f"  release seen in {ok.sum()} of {nb - 1} cols; mean time after the start of the F loop {np.mean(seen[ok] - f0[ok]):.2f} us")
