@@ -9,6 +9,7 @@ where a node changed, and the arithmetic runs in the HIP kernels of libttk.so.
 Sums over mini-batches in the reference are sums over samples, so one pass over
 the full data gives the same Gram matrix, right-hand side and (batch-mean) loss.
 """
+import os
 import time
 from collections import deque
 
@@ -37,6 +38,10 @@ class TensorNetwork:
         self._shard = None
         self._pending = None
         self._spec = None
+        self._streams = None        # (caller's stream, pipeline stream) while accumulating_swipe runs on two streams
+        self._nodes_ready = None    # event on the pipeline stream: every node as of the last finished update
+        self._in_user = False       # inside a user callback of that sweep
+        self._sweep_d = None        # the data set that sweep works on
         self._engine = self._make_engine()
 
     def _make_engine(self):
@@ -95,7 +100,55 @@ class TensorNetwork:
         return self._engine.data_for(x, shard=shard)
 
     def _predict(self, d, k=None):
+        self._user_guard(d)
         return self._engine.predict(d, k)
+
+    # ------------------------------------------------------------------ two-stream sweep
+    # accumulating_swipe queues its own work (local problems, solves, node updates, gauge moves) on a
+    # pipeline stream and runs the user's callbacks on the caller's stream.  A callback that evaluates the
+    # model on held-out data and reads a score back then waits for its own few kernels only, not for the
+    # next node's Gram matrix that is already queued behind the update it looks at; the host is back in time
+    # to queue the next solve while that Gram matrix is still being computed.
+    _pipe_streams = {}
+
+    def _two_streams(self, device):
+        """(caller's stream, pipeline stream) for a sweep on `device`, or None where one stream is used:
+        CPU tensors, a sweep started from inside a callback of another sweep, engines other than the chain
+        engine (their callbacks may reach member networks this guard does not see)."""
+        if device.type != 'cuda' or self._streams is not None or type(self._engine) is not ChainEngine \
+                or os.environ.get("TTK_ONE_STREAM") == "1":
+            return None
+        user = torch.cuda.current_stream(device)
+        pipe = TensorNetwork._pipe_streams.get(device)
+        if pipe is None:
+            pipe = TensorNetwork._pipe_streams[device] = torch.cuda.Stream(device)
+        return user, pipe
+
+    def _user_guard(self, d=None, heavy=False):
+        """Called by everything a callback may reach.  Work on other data (a validation set) runs beside
+        the pipeline; anything that touches the sweep's own data set or a shared workspace (Gram,
+        dense matrix, Cholesky storage) first lets the caller's stream wait for the pipeline."""
+        if self._in_user and self._streams is not None and (heavy or d is None or d is self._sweep_d):
+            user, pipe = self._streams
+            user.wait_stream(pipe)
+
+    def _user(self, fn, *args):
+        """A user callback of the two-stream sweep: on the caller's stream, after the last node update;
+        whatever it queued is waited for before the pipeline goes on."""
+        if self._streams is None:
+            return fn(*args)
+        user, pipe = self._streams
+        if self._nodes_ready is not None:
+            user.wait_event(self._nodes_ready)
+        else:
+            user.wait_stream(pipe)
+        self._in_user = True
+        try:
+            with torch.cuda.stream(user):
+                return fn(*args)
+        finally:
+            self._in_user = False
+            pipe.wait_stream(user)
 
     def _shape_output(self, y):
         """(S, C) -> TensorNode labelled like the reference's forward output."""
@@ -113,6 +166,7 @@ class TensorNetwork:
 
     def recompute_all_stacks(self, exclude_nodes=set()):
         if self._current is not None:
+            self._user_guard(self._current)
             self._engine.refresh(self._current)
 
     def left_update_stacks(self, node):
@@ -179,6 +233,7 @@ class TensorNetwork:
         if self._current is None:
             raise RuntimeError("no input bound: call forward(x) / set_input(x) first")
         d = self._current
+        self._user_guard(d, heavy=True)
         return d, self._engine.local(d, node)
 
     def _gram_matrix(self, lp, H, scale=None, ridge=0.0, out=None):
@@ -303,11 +358,12 @@ class TensorNetwork:
     def _site_front(self, d, node, y, loss_fn, batch_size, want_loss):
         """Everything of a node update that does not move a node: local problem, loss, gradient,
         right-hand side and Gram matrix (into the workspace), all queued on the stream."""
+        self._user_guard(d, heavy=True)
         lp = self._engine.local(d, node)
         y_pred = self._engine.output_at(d, node, lp)  # the output is linear in every single node
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
-        total = self._batch_mean_loss(d, loss, batch_size) if want_loss else None
+        total = self._host_scalar(self._batch_mean_loss(d, loss, batch_size)) if want_loss else None
         b = lp.rhs(g)
         front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None, "gen": None}
         sym = self._hessian_symmetric(H, sharded=d.sharded)
@@ -387,6 +443,18 @@ class TensorNetwork:
                 self._pend_pivot_check(info, node)
         node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return total
+
+    @staticmethod
+    def _host_scalar(t):
+        """A device scalar on its way to pinned host memory, with the event that says it has arrived:
+        reading it later waits for this copy only, not for what has been queued behind it."""
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+            return t
+        host = torch.empty((), dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        return (host, ready)
 
     def _mark(self, name):
         """Phase marks for benchmarking: with `self._marks` set to a list, a device event is recorded
@@ -488,7 +556,6 @@ class TensorNetwork:
         start = time.time() if timeout is not None else None
         want_loss = loss_callback is not None or (verbose and verbose > 1)
         last = {"fwd": None, "bwd": None}
-        NS = 0
 
         def eps_for(NS):
             e = eps[NS] if isinstance(eps, list) else eps
@@ -514,6 +581,9 @@ class TensorNetwork:
                                                  min_norm, max_norm, want_loss)
                     if orthonormalize:
                         (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
+                    if self._streams is not None:   # what the callbacks of this update may look at is queued
+                        self._nodes_ready = torch.cuda.Event()
+                        self._nodes_ready.record()
                     if i + 1 < len(order) and method != 'gradient':
                         # the next node's Gram matrix is queued before the host waits for the pivot flag
                         # and before the callbacks take the host (see _speculate)
@@ -526,46 +596,65 @@ class TensorNetwork:
                     if verbose and verbose > 0:
                         print(f"Singular system for node {node.name}")
                     return False
-                if isinstance(loss, torch.Tensor):
+                if isinstance(loss, tuple):
+                    loss[1].synchronize()
+                    loss = loss[0].item()
+                elif isinstance(loss, torch.Tensor):
                     loss = loss.item()
                 if verbose and verbose > 1:
                     print(f"NS: {NS}, {'Left' if which == 'fwd' else 'Right'} loss ({node.name}):", loss, f" (eps: {eps_})")
                 if loss_callback is not None:
-                    loss_callback(NS, node, loss)
-                if convergence_criterion is not None and convergence_criterion():
+                    self._user(loss_callback, NS, node, loss)
+                if convergence_criterion is not None and self._user(convergence_criterion):
                     if verbose and verbose > 0:
                         print('Converged (left pass)' if which == "fwd" else 'Converged (right pass)')
                     if block_callback is not None:
-                        block_callback(NS, node)
+                        self._user(block_callback, NS, node)
                     return True
                 if block_callback is not None:
-                    block_callback(NS, node)
+                    self._user(block_callback, NS, node)
             return None
 
         # index used for per-node eps lists: position in the un-reversed order (network.py:429,531)
         reverse_gauge_index = {"fwd": direction != 'l2r', "bwd": direction != 'r2l'}
-        for _ in range(num_swipes):
-            if node_order is not None:
-                first = node_order[0] if isinstance(node_order, tuple) else node_order
-            else:
-                first = self.train_nodes
-            first = list(first) if direction == 'l2r' else list(reversed(list(first)))
-            r = run_pass(first, "fwd", "bwd", NS, eps_for(NS), reverse_gauge=False)
-            if r is not None:
-                return r
-            NS += 1
-            if skip_second:
-                continue
-            if node_order is not None:
-                second = node_order[1] if isinstance(node_order, tuple) else list(reversed(list(node_order)))
-            else:
-                second = self.train_nodes
-            second = list(second) if direction == 'r2l' else list(reversed(list(second)))
-            r = run_pass(second, "bwd", "fwd", NS, eps_for(NS), reverse_gauge=True)
-            if r is not None:
-                return r
-            NS += 1
-        return True
+
+        def swipes():
+            NS = 0
+            for _ in range(num_swipes):
+                if node_order is not None:
+                    first = node_order[0] if isinstance(node_order, tuple) else node_order
+                else:
+                    first = self.train_nodes
+                first = list(first) if direction == 'l2r' else list(reversed(list(first)))
+                r = run_pass(first, "fwd", "bwd", NS, eps_for(NS), reverse_gauge=False)
+                if r is not None:
+                    return r
+                NS += 1
+                if skip_second:
+                    continue
+                if node_order is not None:
+                    second = node_order[1] if isinstance(node_order, tuple) else list(reversed(list(node_order)))
+                else:
+                    second = self.train_nodes
+                second = list(second) if direction == 'r2l' else list(reversed(list(second)))
+                r = run_pass(second, "bwd", "fwd", NS, eps_for(NS), reverse_gauge=True)
+                if r is not None:
+                    return r
+                NS += 1
+            return True
+
+        streams = self._two_streams(device) if method != 'gradient' else None
+        if streams is None:
+            return swipes()
+        user, pipe = streams
+        pipe.wait_stream(user)
+        self._streams, self._nodes_ready, self._sweep_d = streams, None, d
+        try:
+            with torch.cuda.stream(pipe):
+                return swipes()
+        finally:
+            self._streams = self._nodes_ready = self._sweep_d = None
+            user.wait_stream(pipe)
 
     def gradient_swipe(self, x, y_true, loss_fn, *args, **kwargs):
         """Name used by one caller of the reference that no reference class defines
@@ -642,6 +731,7 @@ class TensorNetwork:
     # ------------------------------------------------------------------ matrix-free sweeps
     def _krylov_setup(self, d, node, y, loss_fn, batch_size, want_loss):
         """RHS phase shared by lanczos_swipe / scipy_swipe (tensor/network.py:746-767)."""
+        self._user_guard(d, heavy=True)
         lp = self._engine.local(d, node)
         y_pred = self._engine.output_at(d, node, lp)
         loss, grad, hess = loss_fn.forward(self._shape_output(y_pred).tensor, y)

@@ -200,3 +200,57 @@ def test_legacy_kwargs_and_errors():
         assert list(n.dim_labels) == labels and torch.equal(n.tensor, t)
     assert tn.accumulating_swipe(x[:2], y[:2], SquareBregFunction(), method="cholesky") is False
     assert tn.accumulating_swipe(x, y, SquareBregFunction(), method="ridge_cholesky", eps=1.0, timeout=0.0) is False
+
+
+@gpu
+def test_two_stream_sweep_equals_one_stream(monkeypatch):
+    """accumulating_swipe runs its own work on a pipeline stream and the callbacks on the caller's stream.
+    Callbacks that evaluate held-out data, the training data and a Gram matrix (which shares its workspace
+    with the sweep) must see exactly what they see when everything runs on one stream."""
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    torch.set_default_dtype(torch.float64)
+    N, r, p, S = 6, 8, 4, 3000
+    g = torch.Generator().manual_seed(3)
+    x = [(torch.rand(S, p, generator=g) * 2 - 1).to(DEV) for _ in range(N)]
+    xv = [(torch.rand(500, p, generator=g) * 2 - 1).to(DEV) for _ in range(N)]
+    y = torch.randn(S, 1, generator=g).to(DEV)
+
+    def run(one_stream):
+        if one_stream:
+            monkeypatch.setenv("TTK_ONE_STREAM", "1")
+        else:
+            monkeypatch.delenv("TTK_ONE_STREAM", raising=False)
+        layer = TensorTrainLayer(N, r, p, output_shape=1, constrict_bond=True, seed=5).to(DEV)
+        tn = layer.tensor_network
+        seen = []
+
+        def loss_cb(NS, node, loss):
+            seen.append(("loss", torch.tensor(loss)))
+
+        def conv():
+            seen.append(("val", tn.forward_batch(xv, 128).cpu()))
+            return False
+
+        def block_cb(NS, node):
+            yp = tn.forward(x, to_tensor=True)              # the sweep's own data set
+            loss, gr, H = SquareBregFunction().forward(yp, y)
+            A, b = tn.get_A_b(tn.train_nodes[1], gr, H)     # shares the Gram workspace with the queued update
+            seen.append(("train", yp.cpu()))
+            seen.append(("A", A.cpu()))
+            seen.append(("b", b.cpu()))
+
+        ok = tn.accumulating_swipe(x, y, SquareBregFunction(), batch_size=512, num_swipes=1, method="ridge_cholesky",
+                                   eps=1.0, eps_decay=0.5, orthonormalize=True, loss_callback=loss_cb,
+                                   convergence_criterion=conv, block_callback=block_cb)
+        assert ok
+        torch.cuda.synchronize()
+        return seen, [n.tensor.cpu() for n in tn.main_nodes]
+
+    seen1, nodes1 = run(True)
+    seen2, nodes2 = run(False)
+    assert len(seen1) == len(seen2) and len(seen1) > 20
+    for (k1, a), (k2, b) in zip(seen1, seen2):
+        assert k1 == k2 and torch.equal(a, b), k1
+    for a, b in zip(nodes1, nodes2):
+        assert torch.equal(a, b)
