@@ -19,6 +19,7 @@ class Shard:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self._index = {}   # (device, indices) -> device index tensor: built once, no host-to-device copy per update
 
     def bounds(self, S, rank=None):
         r = self.rank if rank is None else rank
@@ -29,6 +30,15 @@ class Shard:
     def rows(self, t):
         lo, hi = self.bounds(t.shape[0])
         return t[lo:hi]
+
+    def _index_tensor(self, values, device):
+        key = (device, tuple(values))
+        t = self._index.get(key)
+        if t is None:
+            if len(self._index) > 64:
+                self._index.clear()
+            t = self._index[key] = torch.tensor(list(values), dtype=torch.int64, device=device)
+        return t
 
     def allreduce_sum_(self, t):
         """In-place sum over ranks.  RCCL handles device tensors; under gloo (CPU
@@ -91,11 +101,11 @@ class Shard:
         npk = G3.shape[0] * len(reps) * G3.shape[2]
         msg = torch.empty(npk + nb, dtype=G.dtype, device=G.device)
         packed = msg[:npk].view(G3.shape[0], len(reps), G3.shape[2])
-        torch.index_select(G3, 1, torch.tensor(reps, device=G.device), out=packed)
+        torch.index_select(G3, 1, self._index_tensor(reps, G.device), out=packed)
         if nb:
             msg[npk:].copy_(b.reshape(-1))
         self.allreduce_sum_(msg)
-        torch.index_select(packed, 1, torch.tensor([pos[int(v)] for v in rep], device=G.device), out=G3)
+        torch.index_select(packed, 1, self._index_tensor([pos[int(v)] for v in rep], G.device), out=G3)
         if nb:
             b.copy_(msg[npk:].reshape(b.shape))
         return G
