@@ -176,6 +176,13 @@ int64_t ttk_chol_ws_bytes(int n);
 int ttk_chol_prepare_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
                          const double* b, const double* w, void* chol_ws, void* stream);
 int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream);
+/* ttk_chol_prepare_f64 + ttk_chol_solve_f64 in one call (tensor/network.py:296-316 on the matrix of
+ * network.py:207-215).  From order 2048 on, where the factorisation is one launch of tile tasks, each task
+ * takes its tile of A/scale[0] + ridge*I straight from the compressed Gram: the expanded lower triangle
+ * (4 n^2 bytes written and read back) never exists.  Same values, same operations, same result bits as the
+ * two calls; below that order the two calls are what runs. */
+int ttk_chol_solve_gram_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
+                            const double* b, const double* w, void* chol_ws, double* x, int* info, void* stream);
 /* How ttk_chol_solve_f64 factorises (same call, same result up to rounding): 0 = one launch per
  * panel and trailing update; 1 = the whole factorisation as one launch of tile tasks that wait on
  * each other through progress words in the workspace; -1 (default) = 1 from 32 block columns (order 2048) on,

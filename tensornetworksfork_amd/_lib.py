@@ -46,6 +46,7 @@ SIGNATURES = {
     "ttk_chol_ws_bytes": (_i64, [_int]),
     "ttk_chol_prepare_f64": (_int, [_c_dp, _int, _int, _int, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),
     "ttk_chol_solve_f64": (_int, [_c_dp, _int, _c_dp, _c_dp, _c_dp]),
+    "ttk_chol_solve_gram_f64": (_int, [_c_dp, _int, _int, _int, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "ttk_chol_mode": (_int, [_int]),
     "ttk_qr_lds_bytes": (_i64, [_int, _int]),
     "ttk_qr_f64": (_int, [_c_dp, _int, _int, _c_dp, _c_dp, _c_dp]),

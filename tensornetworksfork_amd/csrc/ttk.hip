@@ -3117,9 +3117,40 @@ __device__ __forceinline__ int dag_factor(int j, int nb, unsigned* ctl, __amdgpu
   return badcol;
 }
 
+// Where the tiles of A come from.  With G set the factorisation reads A straight from the compressed Gram,
+//   A[(l,pp,r)][(m,q,t)] = G[a(l,m)][b(pp,q)][c(r,t)] / scale + ridge (row == col),   identity beyond order D,
+// exactly what gram_expand_lower_kernel would have written into the storage first (same operations in the same
+// order, so the same bits): the 8 D^2 / 2 bytes of the expanded lower triangle are then never written or read.
+// The right-hand side (block row nb) always comes from the storage.
+struct DagGram {
+  const double* G;
+  const double* scale;
+  double ridge;
+  int rl, p, rr, sym, NX, NRpad, D;
+  float inv_rr, inv_p;   // 1 / rr, 1 / p: quotients of indices below 2^21 by one multiply (see dag_div)
+};
+// x / d for 0 <= x < 2^21 with inv = 1.0f / d: (x + 0.5) * inv is at least 0.5 / d away from every integer, the
+// rounding error of the product stays below x * 2^-22 < 0.5 / d.
+__device__ __forceinline__ int dag_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+template <bool LAZY>
+__device__ __forceinline__ double dag_a(const double* __restrict__ aug, int ld, const DagGram& gs, int row, int col) {
+  if (!LAZY || row >= ld) return aug[(int64_t)row * ld + col];
+  if (row >= gs.D) return row == col ? 1.0 : 0.0;
+  const int lp = dag_div(row, gs.inv_rr), r = row - lp * gs.rr, l = dag_div(lp, gs.inv_p), pp = lp - l * gs.p;
+  const int mq = dag_div(col, gs.inv_rr), t = col - mq * gs.rr, m = dag_div(mq, gs.inv_p), q = mq - m * gs.p;
+  const int a = gs.sym ? tri_index(min(l, m), max(l, m), gs.rl) : l * gs.rl + m;
+  const int b = tri_index(min(pp, q), max(pp, q), gs.p);
+  const int c = tri_index(min(r, t), max(r, t), gs.rr);
+  double v = gs.G[((int64_t)a * gs.NX + b) * gs.NRpad + c];
+  if (gs.scale) v = v / gs.scale[0];
+  if (row == col) v += gs.ridge;
+  return v;
+}
+
+template <bool LAZY>
 __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ aug, int ld, int nb, unsigned aug_bytes,
                                                           double* __restrict__ Winv, int* __restrict__ info,
-                                                          unsigned* __restrict__ ctl, int nchain) {
+                                                          unsigned* __restrict__ ctl, int nchain, DagGram gs) {
   chol_lds_t R = dagR;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)aug, 0, (int)aug_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw =
@@ -3182,8 +3213,8 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc[0][u][t] = aug[(int64_t)(i * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
-          acc[1][u][t] = aug[(int64_t)(i2 * CHB + r_own) * ld + j * CHB + 16 * u + 4 * t + kq];
+          acc[0][u][t] = dag_a<LAZY>(aug, ld, gs, i * CHB + r_own, j * CHB + 16 * u + 4 * t + kq);
+          acc[1][u][t] = dag_a<LAZY>(aug, ld, gs, i2 * CHB + r_own, j * CHB + 16 * u + 4 * t + kq);
         }
       const int qrow[2] = {i, i2};
       if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j, rowready, ctl, tid) ||
@@ -3229,9 +3260,9 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int c = 16 * u + 4 * t + kq;
-        const double v = aug[(int64_t)(j * CHB + r_own) * ld + j * CHB + c];
-        acc[0][u][t] = c <= r_own ? v : 0.0;   // only the lower triangle of A_jj is stored
-        acc[1][u][t] = aug[(int64_t)((j + 1) * CHB + r_own) * ld + j * CHB + c];
+        const double v = dag_a<LAZY>(aug, ld, gs, j * CHB + r_own, j * CHB + c);
+        acc[0][u][t] = c <= r_own ? v : 0.0;   // only the lower triangle of A_jj is used
+        acc[1][u][t] = dag_a<LAZY>(aug, ld, gs, (j + 1) * CHB + r_own, j * CHB + c);
       }
     {
       // Both tiles up to block column j-2; then the diagonal tile's last term, L_{j,j-1}, which is what the
@@ -3946,7 +3977,7 @@ static int chol_dag_slots() {
   std::lock_guard<std::mutex> lock(mu);
   if (slots[dev] == 0) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     slots[dev] = per_cu * cus;
   }
@@ -3962,9 +3993,9 @@ static int chol_back_substitute(hipStream_t st, double* aug, int ld, int nb, con
   return ttk_launch_status();
 }
 
-int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
-  if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+// gs != nullptr: the matrix is still in the compressed Gram workspace gs->G (see DagGram); the single-launch
+// factorisation reads it from there, the multi-launch one has it expanded into the storage first.
+static int chol_solve_impl(void* chol_ws, int n, double* x, int* info, hipStream_t st, const DagGram* gs) {
   const int nb = (n + CHB - 1) / CHB;
   const int ld = nb * CHB;
   const int nbr = nb + 1;
@@ -3983,12 +4014,19 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
     const int slots = chol_dag_slots();
     int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
     nchain = max(1, min(nchain, slots / 16));   // most of the device must stay with the workers
-    hipLaunchKernelGGL(chol_dag_kernel, dim3((unsigned)slots), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes, invL, info,
-                       ctl, nchain);
+    if (gs)
+      hipLaunchKernelGGL(chol_dag_kernel<true>, dim3((unsigned)slots), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes,
+                         invL, info, ctl, nchain, *gs);
+    else
+      hipLaunchKernelGGL(chol_dag_kernel<false>, dim3((unsigned)slots), dim3(256), 0, st, aug, ld, nb, (unsigned)aug_bytes,
+                         invL, info, ctl, nchain, DagGram{});
     int rc = ttk_launch_status();
     if (rc != TTK_OK) return rc;
     return chol_back_substitute(st, aug, ld, nb, invL, x, n);   // invL already holds the inverses
   }
+  if (gs)
+    hipLaunchKernelGGL(gram_expand_lower_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)ld), dim3(256), 0, st, gs->G,
+                       gs->rl, gs->p, gs->rr, gs->sym, gs->NX, gs->NRpad, gs->scale, gs->ridge, aug, ld);
   // One stream.  (A look-ahead that factorises the next pair of panels on a second,
   // high-priority stream beside the trailing update was measured and gained nothing: the
   // panel workgroups queue behind resident trailing-update workgroups for CU space.)
@@ -4019,6 +4057,36 @@ int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream)
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   return chol_back_substitute(st, aug, ld, nb, invL, x, n);
+}
+
+int ttk_chol_solve_f64(void* chol_ws, int n, double* x, int* info, void* stream) {
+  if (!chol_ws || !x || !info || n < 1) return TTK_EINVAL;
+  return chol_solve_impl(chol_ws, n, x, info, (hipStream_t)stream, nullptr);
+}
+
+int ttk_chol_solve_gram_f64(const void* gram_ws, int rl, int p, int rr, int sym_left, const double* scale, double ridge,
+                            const double* b, const double* w, void* chol_ws, double* x, int* info, void* stream) {
+  if (!gram_ws || !b || !chol_ws || !x || !info || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const GramDims d = gram_dims(1, 1, rl, p, rr, sym_left);
+  const int n = rl * p * rr;
+  const int nb = (n + CHB - 1) / CHB;
+  const int ld = nb * CHB;
+  double* aug = (double*)chol_ws;
+  // the right-hand side row (and the zero rows below it) is all that goes into the storage up front
+  if (hipMemsetAsync(aug + (int64_t)ld * ld, 0, (size_t)CHB * ld * sizeof(double), st) != hipSuccess) return TTK_ELAUNCH;
+  hipLaunchKernelGGL(solve_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, w, scale, ridge,
+                     aug + (int64_t)ld * ld, (int64_t)n);
+  int rc = ttk_launch_status();
+  if (rc != TTK_OK) return rc;
+  DagGram gs;
+  gs.G = (const double*)gram_ws;
+  gs.scale = scale;
+  gs.ridge = ridge;
+  gs.rl = rl; gs.p = p; gs.rr = rr; gs.sym = sym_left; gs.NX = d.NX; gs.NRpad = d.NRpad; gs.D = n;
+  gs.inv_rr = 1.0f / (float)rr;
+  gs.inv_p = 1.0f / (float)p;
+  return chol_solve_impl(chol_ws, n, x, info, st, &gs);
 }
 
 int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {

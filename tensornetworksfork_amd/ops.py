@@ -401,6 +401,23 @@ def chol_solve_gram(ws, b, w=None, scale=None, ridge=0.0):
         cw = torch.empty((nbytes + 7) // 8, dtype=F64, device=ws.buf.device)
         _chol_ws[key] = cw
     st = _stream(ws.buf)
+    x = torch.empty((D,), dtype=F64, device=ws.buf.device)
+    info = torch.empty((), dtype=torch.int32, device=ws.buf.device)
+    rc = _lib.lib().ttk_chol_solve_gram_f64(ws.buf.data_ptr(), rl, p, rr, sym, None if scale is None else _chk(scale, "scale"),
+                                            float(ridge), _chk(b, "b"), None if w is None else _chk(w, "w"),
+                                            cw.data_ptr(), x.data_ptr(), info.data_ptr(), st)
+    _lib.check(rc, "ttk_chol_solve_gram_f64")
+    return x, info
+
+
+def chol_solve_gram_two_calls(ws, b, w=None, scale=None, ridge=0.0):
+    """chol_solve_gram through ttk_chol_prepare_f64 + ttk_chol_solve_f64 (the matrix is expanded into the
+    Cholesky storage first); what the one-call form is checked against."""
+    _, _, rl, p, rr, sym = ws.dims
+    D = rl * p * rr
+    nbytes = int(_lib.lib().ttk_chol_ws_bytes(D))
+    cw = torch.empty((nbytes + 7) // 8, dtype=F64, device=ws.buf.device)
+    st = _stream(ws.buf)
     rc = _lib.lib().ttk_chol_prepare_f64(ws.buf.data_ptr(), rl, p, rr, sym, None if scale is None else _chk(scale, "scale"),
                                          float(ridge), _chk(b, "b"), None if w is None else _chk(w, "w"),
                                          cw.data_ptr(), st)

@@ -235,6 +235,37 @@ def test_cholesky_solve(S, C, rl, p, rr):
 
 
 @gpu
+@pytest.mark.parametrize("S,C,rl,p,rr,mode", [(600, 1, 16, 6, 16, 1), (900, 1, 16, 6, 16, -1), (700, 2, 7, 5, 9, 1),
+                                              (800, 1, 20, 3, 20, 1), (4000, 1, 32, 3, 32, -1)])
+def test_cholesky_from_gram_equals_two_calls(S, C, rl, p, rr, mode):
+    """ttk_chol_solve_gram_f64 (the single-launch factorisation takes its tiles straight from the compressed Gram)
+    against ttk_chol_prepare_f64 + ttk_chol_solve_f64 (matrix expanded into the storage first): the same bits,
+    for orders that are and are not multiples of the 64 block, one and several outputs, and on the multi-launch
+    route (order below the threshold with the default mode), where the one call expands internally."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    L, X, R = _rand((S, C, rl), 51).to(dev), _rand((S, p), 52).to(dev), _rand((S, rr), 53).to(dev)
+    Hh = _rand((S, C, C), 55)
+    H = (Hh @ Hh.transpose(1, 2) + 0.1 * torch.eye(C, dtype=torch.float64)).contiguous().to(dev)
+    w = _rand((rl, p, rr), 56).to(dev)
+    ws = ops.gram(L, H, X, R, sym=True)
+    b = ops.rhs(L, X, R, _rand((S, C), 54).to(dev))
+    scale = ops.gram_scale(ws)
+    prev = ops.chol_mode(mode)
+    try:
+        for ridge in (2.0, 0.02):
+            x1, i1 = ops.chol_solve_gram(ws, b, w, scale, ridge)
+            x2, i2 = ops.chol_solve_gram_two_calls(ws, b, w, scale, ridge)
+            assert int(i1.item()) == 0 and int(i2.item()) == 0
+            assert torch.equal(x1, x2), (rl * p * rr, ridge)
+        x1, i1 = ops.chol_solve_gram(ws, b, None, None, 0.5)      # no scale, no ridge weights
+        x2, i2 = ops.chol_solve_gram_two_calls(ws, b, None, None, 0.5)
+        assert int(i1.item()) == int(i2.item()) == 0 and torch.equal(x1, x2)
+    finally:
+        ops.chol_mode(prev)
+
+
+@gpu
 @pytest.mark.parametrize("S,C,rl,p,rr", [(300, 1, 4, 16, 4), (1000, 3, 24, 50, 24), (777, 9, 48, 65, 48), (129, 2, 1, 17, 5),
                                          (500, 1, 7, 130, 9), (260, 2, 3, 256, 2), (64, 1, 5, 33, 1)])
 def test_rhs_feature_matches_oracle(S, C, rl, p, rr):
