@@ -239,6 +239,9 @@ int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* 
                           int64_t D, void* stream);
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, void* stream);
+/* out[row] = <J[row, :], v> for explicit Jacobian rows J (rows = S*C, D entries each): the J v of a narrow node
+ * (a conv filter node, tensor/network.py:101-113 with 788) in one pass over J at memory speed. */
+int ttk_rows_dot_f64(const double* J, const double* v, double* out, int64_t rows, int D, void* stream);
 
 /* ---- sites with many features (conv-featurised / operator columns) and explicit Jacobian rows ----
  *

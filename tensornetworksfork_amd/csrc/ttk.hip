@@ -1947,6 +1947,88 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict
   }
 }
 
+// The same step for vectors beyond one workgroup's registers (cores of conv tensor trains: 48 x 65 x 48), spread
+// over LZW_WG workgroups in four launches; the partial sums wait in the first 2 LZW_WG entries of v_next, which is
+// written last:
+//   <0>  w -= beta[j-1] v_prev, partial <w, v_cur>            -> v_next[wg]
+//   <1>  alpha = sum of those (every workgroup, fixed order); w -= alpha v_cur, partial <w, w> -> v_next[LZW_WG + wg]
+//   lanczos_wide_scalars_kernel (one workgroup): alphas[j-1], betas[j] = sqrt(sum)
+//   <2>  v_next = w / betas[j]
+#define LZW_WG 128
+template <int PHASE>
+__global__ __launch_bounds__(256) void lanczos_wide_kernel(double* __restrict__ w, const double* __restrict__ v_prev,
+                                                            const double* __restrict__ v_cur, double* __restrict__ v_next,
+                                                            const double* __restrict__ betas, int j, int64_t D) {
+  __shared__ double red[4];
+  const int64_t per = ((D + LZW_WG - 1) / LZW_WG + 1) & ~(int64_t)1;
+  const int64_t k0 = (int64_t)blockIdx.x * per, k1 = min(D, k0 + per);
+  if (PHASE == 0) {
+    const double bprev = betas[j - 1];
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      double wk = w[k];
+      if (v_prev) {
+        wk -= bprev * v_prev[k];
+        w[k] = wk;
+      }
+      acc += wk * v_cur[k];
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) v_next[blockIdx.x] = acc;
+  } else if (PHASE == 1) {
+    double a = threadIdx.x < LZW_WG ? v_next[threadIdx.x] : 0.0;
+    a = block_sum_256(a, red);
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      const double wk = w[k] - a * v_cur[k];
+      w[k] = wk;
+      acc += wk * wk;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) v_next[LZW_WG + blockIdx.x] = acc;
+  } else {
+    const double bj = betas[j];
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) v_next[k] = w[k] / bj;
+  }
+}
+__global__ __launch_bounds__(256) void lanczos_wide_scalars_kernel(const double* __restrict__ v_next,
+                                                                    double* __restrict__ alphas, double* __restrict__ betas,
+                                                                    int j) {
+  __shared__ double red[4];
+  const double a = block_sum_256(threadIdx.x < LZW_WG ? v_next[threadIdx.x] : 0.0, red);
+  const double b = block_sum_256(threadIdx.x < LZW_WG ? v_next[LZW_WG + threadIdx.x] : 0.0, red);
+  if (threadIdx.x == 0) {
+    alphas[j - 1] = a;
+    betas[j] = sqrt(b);
+  }
+}
+
+// out[row] = <J[row, :], v>: explicit Jacobian rows of a narrow node (a conv filter) times a vector.  LPR lanes
+// share a row (consecutive entries of a row go to consecutive lanes: a wave reads 64 / LPR whole rows, which lie
+// back to back in memory), the vector sits in registers, one pass over J at memory speed.
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict__ J, const double* __restrict__ v,
+                                                        double* __restrict__ out, int64_t rows, int D) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  constexpr int NV = 4;   // entries of v per lane held in registers (D <= NV * LPR), the rest read again
+  double vr[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) vr[u] = sub + u * LPR < D ? v[sub + u * LPR] : 0.0;
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t row = min(r0 + rsel, rows - 1);
+    const double* jr = J + row * D;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) acc += sub + u * LPR < D ? jr[sub + u * LPR] * vr[u] : 0.0;
+    for (int d = sub + NV * LPR; d < D; d += LPR) acc += jr[d] * v[d];
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0 && r0 + rsel < rows) out[r0 + rsel] = acc;
+  }
+}
+
 // The vector half of one MINRES iteration (Paige & Saunders, as scipy.sparse.linalg.minres runs it
 // without shift or preconditioner) in one workgroup; every scalar of the recurrence lives in `st`
 // on the device, so the host never reads anything inside the loop.  On entry y = A v.
@@ -4282,9 +4364,34 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
   if (D <= 8192)
     hipLaunchKernelGGL(lanczos_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
                        alphas, betas, j, D);
-  else
+  else if (D < 2 * LZW_WG * 32) {
     hipLaunchKernelGGL(lanczos_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
                        alphas, betas, j, D);
+  } else {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lanczos_wide_kernel<0>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
+    hipLaunchKernelGGL(lanczos_wide_kernel<1>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
+    hipLaunchKernelGGL(lanczos_wide_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)v_next, alphas, betas, j);
+    hipLaunchKernelGGL(lanczos_wide_kernel<2>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
+  }
+  return ttk_launch_status();
+}
+
+int ttk_rows_dot_f64(const double* J, const double* v, double* out, int64_t rows, int D, void* stream) {
+  if (!J || !v || !out || rows < 1 || D < 1) return TTK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 32) {
+    const int64_t waves = (rows + 7) / 8;
+    hipLaunchKernelGGL(rows_dot_kernel<8>, dim3((unsigned)min((int64_t)4096, (waves + 3) / 4)), dim3(256), 0, st, J, v, out,
+                       rows, D);
+  } else if (D <= 64) {
+    const int64_t waves = (rows + 3) / 4;
+    hipLaunchKernelGGL(rows_dot_kernel<16>, dim3((unsigned)min((int64_t)4096, (waves + 3) / 4)), dim3(256), 0, st, J, v, out,
+                       rows, D);
+  } else {
+    hipLaunchKernelGGL(rows_dot_kernel<64>, dim3((unsigned)min((int64_t)4096, (rows + 3) / 4)), dim3(256), 0, st, J, v, out,
+                       rows, D);
+  }
   return ttk_launch_status();
 }
 

@@ -510,6 +510,15 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
     return v_next
 
 
+def rows_dot(J, v):
+    """u (S, C) = J v for explicit Jacobian rows J (S, C, D)."""
+    S, C, D = J.shape
+    out = torch.empty((S, C), dtype=F64, device=J.device)
+    rc = _lib.lib().ttk_rows_dot_f64(_chk(J, "J"), _chk(v, "v", (D,)), out.data_ptr(), S * C, D, _stream(J))
+    _lib.check(rc, "ttk_rows_dot_f64")
+    return out
+
+
 def gl(g, L):
     """GL (S,rl) = sum_c g[s,c] L[s,c,l]."""
     S, C, rl = L.shape

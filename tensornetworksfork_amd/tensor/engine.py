@@ -195,8 +195,7 @@ class LocalProblem:
         """u[s,c] = J v."""
         if self.J is not None:
             if self.D <= DENSE_ROWS_KERNEL_MAX_D:
-                one = _ones_col(self.S, v.device)
-                return ops.env_step_left(self.J.contiguous(), one, v.reshape(self.D, 1, 1).contiguous()).reshape(self.S, self.C)
+                return ops.rows_dot(self.J.contiguous(), v.reshape(self.D).contiguous())
             return (self._jt() * v.reshape(self.D, 1)).sum(dim=0).reshape(self.S, self.C)
         v = v.reshape(self.shape)
         u = None

@@ -185,6 +185,10 @@ def gl(g, L):
     return torch.einsum('sc,scl->sl', g, L)
 
 
+def rows_dot(J, v):
+    return torch.einsum('scd,d->sc', J, v)
+
+
 def cg_update(x, r, p, q, state):
     rho, atol = state[0].clone(), state[1]
     if bool(rho.sqrt() < atol):
@@ -276,7 +280,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rhs_supported rhs_feature").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rhs_supported rhs_feature").split()
 
 
 def install(monkeypatch):

@@ -612,3 +612,45 @@ def test_gemm_tn_and_dense_cholesky(n, D1, D2):
         assert G.rel_err(x, x_r) < 1e-9
         x, info = ops.chol_solve_dense(Gm.to(dev), b.to(dev), None, -5.0)
         assert int(info.item()) >= 1
+
+
+@gpu
+@pytest.mark.parametrize("S,C,D", [(1000, 9, 49), (54001, 9, 17), (777, 1, 5), (300, 3, 33), (129, 2, 128), (64, 10, 1)])
+def test_rows_dot(S, C, D):
+    """J v for explicit rows (filter nodes of a conv tensor train) against a float64 CPU product."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    J, v = _rand((S, C, D), 71), _rand((D,), 72)
+    u = ops.rows_dot(J.to(dev), v.to(dev))
+    ref = torch.einsum('scd,d->sc', J, v)
+    assert G.rel_err(u, ref) < 1e-13
+
+
+@gpu
+@pytest.mark.parametrize("D", [9000, 28800, 149760])
+def test_lanczos_update_wide(D):
+    """The Lanczos vector step spread over many workgroups (vectors beyond one workgroup's registers) against the
+    recurrence written out on the CPU, first iteration (no v_prev) and a later one; repeatable bit for bit."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    w0, vp, vc = _rand((D,), 81), _rand((D,), 82), _rand((D,), 83)
+    vc = vc / vc.norm()
+    for j, prev in ((1, None), (3, vp)):
+        betas = torch.zeros(8, dtype=torch.float64)
+        betas[j - 1] = 0.37
+        alphas = torch.zeros(8, dtype=torch.float64)
+        outs = []
+        for _ in range(2):
+            w, al, be = w0.clone().to(dev), alphas.clone().to(dev), betas.clone().to(dev)
+            vn = ops.lanczos_update(w, None if prev is None else prev.to(dev), vc.to(dev), al, be, j)
+            outs.append((w.cpu(), vn.cpu(), al.cpu(), be.cpu()))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        wr = w0.clone() if prev is None else w0 - 0.37 * prev
+        a_ref = wr @ vc
+        wr = wr - a_ref * vc
+        b_ref = wr.norm()
+        w, vn, al, be = outs[0]
+        assert abs(al[j - 1] - a_ref) <= 1e-12 * max(1.0, abs(a_ref))
+        assert abs(be[j] - b_ref) <= 1e-12 * b_ref
+        assert G.rel_err(w, wr) < 1e-12 and G.rel_err(vn, wr / b_ref) < 1e-12
