@@ -242,6 +242,16 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
 /* out[row] = <J[row, :], v> for explicit Jacobian rows J (rows = S*C, D entries each): the J v of a narrow node
  * (a conv filter node, tensor/network.py:101-113 with 788) in one pass over J at memory speed. */
 int ttk_rows_dot_f64(const double* J, const double* v, double* out, int64_t rows, int D, void* stream);
+/* q (D) = J^T H J v for explicit rows J (S, C, D <= 128) and per-sample Hessians H (S, C, C): the operator handed to
+ * the Lanczos / Krylov solvers for a narrow node (tensor/network.py:788-789 with the Jacobian of 101-113), one pass
+ * over J; the workspace (ttk_rows_matvec_ws_bytes) holds one partial q per workgroup, summed in fixed order. */
+int64_t ttk_rows_matvec_ws_bytes(int64_t S, int C, int D);
+int ttk_rows_matvec_f64(const double* J, const double* H, const double* v, double* q, int64_t S, int C, int D, void* ws,
+                        int64_t ws_bytes, void* stream);
+/* GL (S, rl) = L_s^T H_s (L_s z_s) per sample, L (S, C, rl <= 128), z (S, rl): the prediction from the contracted
+ * environments, the Hessian product and the g.L factor of the right-hand side (the middle of the two einsums at
+ * tensor/network.py:788-789 for a site whose features were contracted first) in one kernel. */
+int ttk_lhl_f64(const double* L, const double* H, const double* z, double* GL, int64_t S, int C, int rl, void* stream);
 
 /* ---- sites with many features (conv-featurised / operator columns) and explicit Jacobian rows ----
  *

@@ -2029,6 +2029,155 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict_
   }
 }
 
+// Per-sample blocks of explicit rows J[s] (C x D, rows back to back in memory) against the per-sample Hessian, one
+// pass over J:  u_s = J_s x_s,  hu_s[d] = sum_c H[s,c,d] u_s[c],  then
+//   MODE 0 (x_s = v for every sample):  q = sum_s J_s^T hu_s       the whole operator v -> J^T H J v of a narrow
+//                                       node (a conv filter node); one partial q per workgroup, summed in fixed
+//                                       order by reduce_slabs_wide_kernel;
+//   MODE 1 (x_s = z[s, :]):             out[s, :] = J_s^T hu_s     with J = L (left environments, C x rl per sample)
+//                                       this is GL = L^T H (L z): prediction, Hessian product and g.L of a
+//                                       many-feature site in one kernel instead of three (L read once, not twice).
+// A workgroup stages NS whole samples (NS C D doubles, one contiguous range) in LDS; LPR lanes share a row in the
+// first product, the Hessian product is one thread per (sample, output), the last product one thread per column.
+template <int MODE, int LPR>
+__global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict__ J, const double* __restrict__ H,
+                                                        const double* __restrict__ x, double* __restrict__ out, int64_t S,
+                                                        int C, int D, int NS) {
+  extern __shared__ double sm[];
+  double* Jc = sm;                         // [NS C][D]
+  double* ub = Jc + (size_t)NS * C * D;    // [NS C]
+  double* hb = ub + NS * C;                // [NS C]
+  double* Hc = hb + NS * C;                // [NS][C][C]
+  double* xs = Hc + (size_t)NS * C * C;    // MODE 0: v [D]; MODE 1: z of the chunk [NS][D]
+  const int tid = threadIdx.x, sub = tid % LPR, grp = tid / LPR;
+  constexpr int NGRP = 256 / LPR;
+  const int64_t nchunks = (S + NS - 1) / NS;
+  double q0 = 0.0, q1 = 0.0;               // MODE 0: columns tid % 64 and 64 + tid % 64, rows tid / 64 mod 4
+  // A chunk travels memory -> registers -> LDS; the registers are filled for chunk c+1 before chunk c is worked
+  // on, so the loads (unconditional, clamped) are in flight during the three phases.
+  double tj[16], th[8], tx[16];
+  auto fetch = [&](int64_t ch) {
+    const int64_t s0 = ch * NS;
+    const int ns = (int)min((int64_t)NS, S - s0);
+    const int n = ns * C * D, nh = ns * C * C, nx = ns * D;
+    const double* sj = J + s0 * C * D;
+    const double* sh = H + s0 * C * C;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tj[u] = sj[min(tid + 256 * u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) th[u] = sh[min(tid + 256 * u, nh - 1)];
+    if (MODE == 1) {
+      const double* sx = x + s0 * D;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tx[u] = sx[min(tid + 256 * u, nx - 1)];
+    }
+  };
+  if (MODE == 0)
+    for (int d = tid; d < D; d += 256) xs[d] = x[d];
+  if ((int64_t)blockIdx.x < nchunks) fetch(blockIdx.x);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t s0 = ch * NS;
+    const int ns = (int)min((int64_t)NS, S - s0);
+    const int rows = ns * C, n = rows * D;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (tid + 256 * u < n) Jc[tid + 256 * u] = tj[u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tid + 256 * u < rows * C) Hc[tid + 256 * u] = th[u];
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (tid + 256 * u < ns * D) xs[tid + 256 * u] = tx[u];
+    }
+    __syncthreads();
+    if (ch + gridDim.x < nchunks) fetch(ch + gridDim.x);
+    // D <= 4 LPR: four predicated steps per row, two rows per pass, all LDS reads of a pass issued together
+    for (int row = grp; row < rows; row += 2 * NGRP) {
+      const int rowb = min(row + NGRP, rows - 1);
+      const double* ja = Jc + row * D;
+      const double* jb = Jc + rowb * D;
+      const double* xa = MODE == 0 ? xs : xs + (row / C) * D;
+      const double* xb = MODE == 0 ? xs : xs + (rowb / C) * D;
+      double pa[4], pb[4], va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d = min(sub + u * LPR, D - 1);
+        pa[u] = ja[d];
+        pb[u] = jb[d];
+        va[u] = xa[d];
+        vb[u] = xb[d];
+      }
+      double acca = 0.0, accb = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = sub + u * LPR < D;
+        acca += ok ? pa[u] * va[u] : 0.0;
+        accb += ok ? pb[u] * vb[u] : 0.0;
+      }
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) {
+        acca += __shfl_xor(acca, off, 64);
+        accb += __shfl_xor(accb, off, 64);
+      }
+      if (sub == 0) {
+        ub[row] = acca;
+        if (row + NGRP < rows) ub[row + NGRP] = accb;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < rows; t += 256) {
+      const int sl = t / C, d = t - sl * C;
+      const double* Hs = Hc + sl * C * C;
+      double acc = 0.0;
+      for (int c = 0; c < C; ++c) acc += Hs[c * C + d] * ub[sl * C + c];
+      hb[t] = acc;
+    }
+    __syncthreads();
+    if (MODE == 0) {
+      const int d = tid & 63, g4 = tid >> 6;
+      const int da = min(d, D - 1), db = min(d + 64, D - 1);
+      const bool oka = d < D, okb = d + 64 < D;
+      int row = g4;
+      for (; row + 12 < rows; row += 16) {   // four rows per pass
+        double h[4], ja[4], jb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          h[u] = hb[row + 4 * u];
+          ja[u] = Jc[(row + 4 * u) * D + da];
+          jb[u] = okb ? Jc[(row + 4 * u) * D + db] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          q0 += oka ? ja[u] * h[u] : 0.0;
+          q1 += jb[u] * h[u];
+        }
+      }
+      for (; row < rows; row += 4) {
+        const double h = hb[row];
+        if (oka) q0 += Jc[row * D + da] * h;
+        if (okb) q1 += Jc[row * D + db] * h;
+      }
+    } else {
+      for (int t = tid; t < ns * D; t += 256) {
+        const int sl = t / D, d = t - sl * D;
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) acc += Jc[(sl * C + c) * D + d] * hb[sl * C + c];
+        out[s0 * D + t] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (MODE == 0) {   // the four row groups of each column, fixed order
+    double* red = sm;   // [4][128]
+    red[(tid >> 6) * 128 + (tid & 63)] = q0;
+    red[(tid >> 6) * 128 + 64 + (tid & 63)] = q1;
+    __syncthreads();
+    for (int d = tid; d < D; d += 256)
+      out[(int64_t)blockIdx.x * D + d] = (red[d] + red[128 + d]) + (red[256 + d] + red[384 + d]);
+  }
+}
+
 // The vector half of one MINRES iteration (Paige & Saunders, as scipy.sparse.linalg.minres runs it
 // without shift or preconditioner) in one workgroup; every scalar of the recurrence lives in `st`
 // on the device, so the host never reads anything inside the loop.  On entry y = A v.
@@ -4374,6 +4523,65 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
     hipLaunchKernelGGL(lanczos_wide_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)v_next, alphas, betas, j);
     hipLaunchKernelGGL(lanczos_wide_kernel<2>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
   }
+  return ttk_launch_status();
+}
+
+// samples per LDS chunk and grid of rows_hjv_kernel
+static bool rows_hjv_dims(int64_t S, int C, int D, int mode, int* NS, int* grid, size_t* lds) {
+  if (S < 1 || C < 1 || C > 32 || D < 1 || D > 128 || (int64_t)C * D > 4096) return false;
+  int ns = 4096 / (C * D);
+  if (ns > 2048 / (C * C)) ns = 2048 / (C * C);   // the Hessians of the chunk sit in LDS too
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  const int64_t nchunks = (S + ns - 1) / ns;
+  *NS = ns;
+  *grid = (int)min((int64_t)1024, nchunks);
+  size_t doubles = (size_t)ns * C * D + 2 * (size_t)ns * C + (size_t)ns * C * C + (mode == 0 ? (size_t)D : (size_t)ns * D);
+  if (doubles < 512) doubles = 512;   // the final reduction of mode 0 reuses the buffer as [4][128]
+  *lds = doubles * sizeof(double);
+  return true;
+}
+static void rows_hjv_launch(int mode, const double* J, const double* H, const double* x, double* out, int64_t S, int C,
+                            int D, int NS, int grid, size_t lds, hipStream_t st) {
+  void (*fn)(const double*, const double*, const double*, double*, int64_t, int, int, int);
+  if (D <= 32)
+    fn = mode ? rows_hjv_kernel<1, 8> : rows_hjv_kernel<0, 8>;
+  else if (D <= 64)
+    fn = mode ? rows_hjv_kernel<1, 16> : rows_hjv_kernel<0, 16>;
+  else
+    fn = mode ? rows_hjv_kernel<1, 32> : rows_hjv_kernel<0, 32>;
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, st, J, H, x, out, S, C, D, NS);
+}
+
+int64_t ttk_rows_matvec_ws_bytes(int64_t S, int C, int D) {
+  int NS, grid;
+  size_t lds;
+  if (!rows_hjv_dims(S, C, D, 0, &NS, &grid, &lds)) return TTK_EINVAL;
+  return (int64_t)grid * D * (int64_t)sizeof(double);
+}
+
+int ttk_rows_matvec_f64(const double* J, const double* H, const double* v, double* q, int64_t S, int C, int D, void* ws,
+                        int64_t ws_bytes, void* stream) {
+  if (!J || !H || !v || !q || !ws) return TTK_EINVAL;
+  int NS, grid;
+  size_t lds;
+  if (!rows_hjv_dims(S, C, D, 0, &NS, &grid, &lds)) return TTK_EINVAL;
+  if (ws_bytes < (int64_t)grid * D * (int64_t)sizeof(double)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  rows_hjv_launch(0, J, H, v, (double*)ws, S, C, D, NS, grid, lds, st);
+  int rc = ttk_launch_status();
+  if (rc != TTK_OK) return rc;
+  hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)ws, grid,
+                     (int64_t)D, (int64_t)D, q, 0);
+  return ttk_launch_status();
+}
+
+int ttk_lhl_f64(const double* L, const double* H, const double* z, double* GL, int64_t S, int C, int rl, void* stream) {
+  if (!L || !H || !z || !GL) return TTK_EINVAL;
+  int NS, grid;
+  size_t lds;
+  if (!rows_hjv_dims(S, C, rl, 1, &NS, &grid, &lds)) return TTK_EINVAL;
+  rows_hjv_launch(1, L, H, z, GL, S, C, rl, NS, grid, lds, (hipStream_t)stream);
   return ttk_launch_status();
 }
 

@@ -519,6 +519,41 @@ def rows_dot(J, v):
     return out
 
 
+_rowsmv_ws = {}
+
+
+def rows_matvec_supported(S, C, D):
+    return int(_lib.lib().ttk_rows_matvec_ws_bytes(S, C, D)) > 0
+
+
+def rows_matvec(J, H, v):
+    """q (D,) = J^T H J v for explicit rows J (S, C, D) and per-sample Hessians H (S, C, C), one pass over J."""
+    S, C, D = J.shape
+    nbytes = int(_lib.lib().ttk_rows_matvec_ws_bytes(S, C, D))
+    if nbytes <= 0:
+        raise _lib.TTKError("ttk_rows_matvec_ws_bytes: extents not supported")
+    key = (J.device, nbytes)
+    ws = _rowsmv_ws.get(key)
+    if ws is None:
+        _rowsmv_ws.clear()
+        ws = _rowsmv_ws[key] = torch.empty((nbytes + 7) // 8, dtype=F64, device=J.device)
+    q = torch.empty((D,), dtype=F64, device=J.device)
+    rc = _lib.lib().ttk_rows_matvec_f64(_chk(J, "J"), _chk(H, "H", (S, C, C)), _chk(v, "v", (D,)), q.data_ptr(), S, C, D,
+                                        ws.data_ptr(), nbytes, _stream(J))
+    _lib.check(rc, "ttk_rows_matvec_f64")
+    return q
+
+
+def lhl(L, H, z):
+    """GL (S, rl) = L_s^T H_s (L_s z_s) per sample: predict + Hessian product + g.L in one kernel."""
+    S, C, rl = L.shape
+    out = torch.empty((S, rl), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_lhl_f64(_chk(L, "L"), _chk(H, "H", (S, C, C)), _chk(z, "z", (S, rl)), out.data_ptr(), S, C, rl,
+                                _stream(L))
+    _lib.check(rc, "ttk_lhl_f64")
+    return out
+
+
 def gl(g, L):
     """GL (S,rl) = sum_c g[s,c] L[s,c,l]."""
     S, C, rl = L.shape
@@ -531,13 +566,14 @@ def gl(g, L):
 _rhsf_ws = {}
 
 
-def rhs_feature(L, X, R, g, out=None, mm32=False):
+def rhs_feature(L, X, R, g, out=None, mm32=False, GL=None):
     """b (rl,p,rr) = sum_{s,c} g[s,c] L[s,c,l] X[s,p] R[s,r] for a site with many features
     (DENSE_MIN_P <= p <= DENSE_MAX_P), features first; with `out` given the result is added to it.
-    `mm32`: float32 matrix arithmetic (float32 models)."""
+    `mm32`: float32 matrix arithmetic (float32 models).  `GL` = g.L (S, rl) if the caller has it already."""
     S, C, rl = L.shape
     p, rr = X.shape[1], R.shape[1]
-    GL = gl(g, L)
+    if GL is None:
+        GL = gl(g, L)
     nbytes = int(_lib.lib().ttk_rhs_feature_ws_bytes(S, rl, p, rr))
     if nbytes < 0:
         raise _lib.TTKError("ttk_rhs_feature_ws_bytes: invalid extents")

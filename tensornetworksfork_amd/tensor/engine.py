@@ -222,6 +222,21 @@ class LocalProblem:
             L, X, R = self.terms[0]
             return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
+        if self.J is not None and self.D <= DENSE_ROWS_KERNEL_MAX_D and H.shape[1] == self.C \
+                and ops.rows_matvec_supported(self.S, self.C, self.D):
+            # explicit rows of a narrow node (conv filter): the whole operator in one pass over the rows
+            J = self.J.contiguous()
+            return lambda v: ops.rows_matvec(J, H, v.reshape(self.D).contiguous()).reshape(self.shape)
+        if self.terms is not None and len(self.terms) == 1 and H.shape[1] == self.C:
+            L, X, R = self.terms[0]
+            if _rhs_features_first(L.shape[2], X.shape[1], R.shape[1]) and L.shape[2] <= 128 and L.shape[1] <= 32 and L.shape[1] * L.shape[2] <= 4096:
+                # one term with many features: features first (J v), then prediction + Hessian + g.L in one kernel,
+                # then the features-first right-hand side
+                def mv1(v):
+                    z = ops.env_step_right(R, X, v.reshape(self.shape).contiguous(), mm32=self.mm32)      # (S, rl)
+                    return ops.rhs_feature(L, X, R, None, mm32=self.mm32, GL=ops.lhl(L, H, z))
+                return mv1
+
         def mv(v):
             u = self.jv(v)
             hu = ops.hess_left(H, u.contiguous().unsqueeze(-1)).squeeze(-1)

@@ -88,7 +88,10 @@ def rhs(L, X, R, g, out=None):
     return r if out is None else out.add_(r)
 
 
-def rhs_feature(L, X, R, g, out=None, mm32=False):
+def rhs_feature(L, X, R, g, out=None, mm32=False, GL=None):
+    if GL is not None:
+        r = torch.einsum('sl,sp,sr->lpr', GL, X, R)
+        return r if out is None else out.add_(r)
     return rhs(L, X, R, g, out=out)
 
 
@@ -189,6 +192,22 @@ def rows_dot(J, v):
     return torch.einsum('scd,d->sc', J, v)
 
 
+def rows_matvec_supported(S, C, D):
+    return D <= 128 and C <= 32 and C * D <= 4096
+
+
+def rows_matvec(J, H, v):
+    u = torch.einsum('scd,d->sc', J, v)
+    hu = torch.einsum('scd,sc->sd', H, u)
+    return torch.einsum('scd,sc->d', J, hu)
+
+
+def lhl(L, H, z):
+    u = torch.einsum('scl,sl->sc', L, z)
+    hu = torch.einsum('scd,sc->sd', H, u)
+    return torch.einsum('scl,sc->sl', L, hu)
+
+
 def cg_update(x, r, p, q, state):
     rho, atol = state[0].clone(), state[1]
     if bool(rho.sqrt() < atol):
@@ -280,7 +299,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rhs_supported rhs_feature").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rows_matvec_supported rows_matvec lhl rhs_supported rhs_feature").split()
 
 
 def install(monkeypatch):

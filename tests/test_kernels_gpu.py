@@ -654,3 +654,25 @@ def test_lanczos_update_wide(D):
         assert abs(al[j - 1] - a_ref) <= 1e-12 * max(1.0, abs(a_ref))
         assert abs(be[j] - b_ref) <= 1e-12 * b_ref
         assert G.rel_err(w, wr) < 1e-12 and G.rel_err(vn, wr / b_ref) < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("S,C,D", [(1000, 9, 49), (20011, 9, 17), (777, 1, 5), (300, 3, 33), (129, 2, 128), (64, 10, 1),
+                                   (513, 32, 128)])
+def test_rows_matvec_and_lhl(S, C, D):
+    """The one-pass operators on per-sample blocks of rows, against float64 CPU products: J^T H J v for a narrow
+    node, and GL = L^T H (L z) per sample; non-symmetric Hessians pin the orientation of the Hessian product."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    J, v, z = _rand((S, C, D), 91), _rand((D,), 92), _rand((S, D), 93)
+    H = _rand((S, C, C), 94)
+    u = torch.einsum('scd,d->sc', J, v)
+    hu = torch.einsum('scd,sc->sd', H, u)
+    q_ref = torch.einsum('scd,sc->d', J, hu)
+    q = ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev))
+    assert G.rel_err(q, q_ref) < 1e-12
+    assert torch.equal(q, ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev)))      # fixed summation order
+    u2 = torch.einsum('scl,sl->sc', J, z)
+    hu2 = torch.einsum('scd,sc->sd', H, u2)
+    gl_ref = torch.einsum('scl,sc->sl', J, hu2)
+    assert G.rel_err(ops.lhl(J.to(dev), H.to(dev), z.to(dev)), gl_ref) < 1e-12
