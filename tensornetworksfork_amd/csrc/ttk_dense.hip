@@ -541,14 +541,42 @@ __global__ __launch_bounds__(256) void patch_contract_kernel(const double* __res
   double* Ms = Xs + P * px;     // [C][P]
   const int64_t s = blockIdx.x;
   const TI* xs = X + s * (int64_t)P * px;
-  for (int k = threadIdx.x; k < P * px; k += 256) Xs[k] = (double)xs[k];
   const double* ms = Mv + s * (int64_t)C * P;
-  for (int k = threadIdx.x; k < C * P; k += 256) Ms[k] = ms[k];
+  // eight unconditional (clamped) loads per thread in flight; the image row first, it is the long one
+  const int nx = P * px, nm = C * P;
+  for (int k0 = threadIdx.x; k0 < nx; k0 += 256 * 8) {
+    TI t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = xs[min(k0 + 256 * u, nx - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 256 * u < nx) Xs[k0 + 256 * u] = (double)t[u];
+  }
+  for (int k0 = threadIdx.x; k0 < nm; k0 += 256 * 4) {
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = ms[min(k0 + 256 * u, nm - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + 256 * u < nm) Ms[k0 + 256 * u] = t[u];
+  }
   __syncthreads();
   for (int o = threadIdx.x; o < C * px; o += 256) {
     const int c = o / px, x = o - c * px;
-    double acc = 0.0;
-    for (int pp = 0; pp < P; ++pp) acc += Ms[c * P + pp] * Xs[pp * px + x];
+    const double* mrow = Ms + c * P;
+    const double* xcol = Xs + x;
+    double a0 = 0.0, a1 = 0.0;   // two chains, LDS reads of four patches issued together
+    int pp = 0;
+    for (; pp + 4 <= P; pp += 4) {
+      const double m0 = mrow[pp], m1 = mrow[pp + 1], m2 = mrow[pp + 2], m3 = mrow[pp + 3];
+      const double x0 = xcol[pp * px], x1 = xcol[(pp + 1) * px], x2 = xcol[(pp + 2) * px], x3 = xcol[(pp + 3) * px];
+      a0 += m0 * x0;
+      a1 += m1 * x1;
+      a0 += m2 * x2;
+      a1 += m3 * x3;
+    }
+    for (; pp < P; ++pp) a0 += mrow[pp] * xcol[pp * px];
+    const double acc = a0 + a1;
     double* dst = J + s * jstride_s + c * jstride_c + x * xstride;
     *dst = accumulate ? *dst + acc : acc;
   }
