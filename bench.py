@@ -217,6 +217,24 @@ def sweep_variant(device, F, y, F_val, y_val, repeats=3):
             "samples_per_sec_sweep": S / t, "repeats": repeats, "val_rmse": hook.last}
 
 
+def dgemm_probe(device, n=8192, reps=3):
+    """Library DGEMM rate on this box right now (torch.mm, fp64): the second denominator for the Gram kernel's
+    rate next to the vendor peak; boxes of one pool differ by a few per cent under fp64 matrix load."""
+    g = torch.Generator(device=device).manual_seed(0)
+    a = torch.rand(n, n, generator=g, dtype=torch.float64, device=device)
+    b = torch.rand(n, n, generator=g, dtype=torch.float64, device=device)
+    torch.mm(a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.mm(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"tflops": 2.0 * n ** 3 / (ms * 1e-3) * 1e-12, "what": f"torch.mm fp64 {n}^3, mean of {reps}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,6 +339,10 @@ def main():
                      "flops_per_launch": gram_flops, "feature_pair_classes": NX,
                      "dense_equivalent_tflops": 2.0 * S_local * D * D / (avg_ms * 1e-3) * 1e-12},
     }
+    if rank == 0 and world == 1:
+        probe = dgemm_probe(device)
+        probe["gram_frac_of_dgemm"] = achieved / probe["tflops"]
+        out["roofline"]["dgemm_probe"] = probe
     if rank == 0 and world == 1 and not args.no_variants:
         out["variants"] = {"cg": cg_variant(device, F, y, steps=10),
                            "sweep": sweep_variant(device, F, y, F_val, y_val)}
