@@ -2827,8 +2827,10 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double* __restrict__ aug
 // product straight from the accumulators) and publishes L_ij.  The diagonal task of column j
 // owns tiles (j, j) and (j+1, j): it accumulates both, factorises the diagonal tile with the
 // 16-column in-register sub-panels of chol_panel_kernel, inverts the factor blockwise (16 x 16
-// triangular inverses by substitution, the other blocks by MFMA products), publishes W_j,
-// finishes its second tile and publishes L_{j+1,j}.  Nothing waits for a kernel boundary: the
+// triangular inverses by substitution, the other blocks by MFMA products), finishes its second
+// tile and publishes L_{j+1,j} (what the next diagonal task waits for), then W_j.  The second tile's
+// last term, whose left factor a worker produces meanwhile, is applied beside the factorisation
+// when it is there in time (dag_late_quarter).  Nothing waits for a kernel boundary: the
 // chain of diagonal tasks runs beside the accumulation of all tiles to its right, which is where
 // the flops are.  The right-hand side rides along as block row nb, as in the multi-launch path.
 //
