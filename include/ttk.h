@@ -235,8 +235,19 @@ int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, i
  * iteration limit) freezes everything, so calls queued behind the last iteration are no-ops.  On exit
  * v is the next Lanczos vector (the next product's operand), x the current solution. */
 int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* stream);
+/* ttk_cg_update_f64 for long vectors (cores of conv tensor trains): with a workspace of ttk_cg_update_ws_bytes(D) bytes
+ * the update of a vector beyond 8192 entries is spread over 128 workgroups (four launches, partial sums in the
+ * workspace, fixed summation order); shorter vectors, or ws = NULL, take the one-workgroup kernel. */
+int64_t ttk_cg_update_ws_bytes(int64_t D);
+int ttk_cg_update_ws_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* ws,
+                         int64_t ws_bytes, void* stream);
 int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
                           int64_t D, void* stream);
+/* ttk_minres_update_f64 for long vectors, as ttk_cg_update_ws_f64: with a workspace of ttk_minres_update_ws_bytes(D) bytes
+ * an iteration on more than 8192 entries runs on 128 workgroups (three vector launches, one scalar launch). */
+int64_t ttk_minres_update_ws_bytes(int64_t D);
+int ttk_minres_update_ws_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
+                             int64_t D, void* ws, int64_t ws_bytes, void* stream);
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, void* stream);
 /* out[row] = <J[row, :], v> for explicit Jacobian rows J (rows = S*C, D entries each): the J v of a narrow node

@@ -1882,6 +1882,55 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
   }
 }
 
+// The same update for vectors beyond one workgroup's registers, spread over CGW_WG workgroups in four launches; `ws`
+// holds 2 CGW_WG partial sums.  Every launch tests the stopping rule on state[0], which only the last one rewrites.
+//   <0> partial <p, q>;  <1> alpha from their sum, x += alpha p, r -= alpha q, partial <r, r>;
+//   <2> beta from their sum, p = r + beta p;  cg_wide_scalars_kernel: state[0] = <r, r>, one more update counted.
+#define CGW_WG 128
+template <int PHASE>
+__global__ __launch_bounds__(256) void cg_wide_kernel(double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                                                       const double* __restrict__ q, double* __restrict__ state,
+                                                       double* __restrict__ ws, int64_t D) {
+  __shared__ double red[4];
+  const double rho = state[0], atol = state[1];
+  if (sqrt(rho) < atol || rho == 0.0) {
+    if (PHASE == 0 && blockIdx.x == 0 && threadIdx.x == 0) state[2] = 1.0;
+    return;
+  }
+  const int64_t per = ((D + CGW_WG - 1) / CGW_WG + 1) & ~(int64_t)1;
+  const int64_t k0 = (int64_t)blockIdx.x * per, k1 = min(D, k0 + per);
+  if (PHASE == 0) {
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) acc += p[k] * q[k];
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+  } else if (PHASE == 1) {
+    const double alpha = rho / block_sum_256(threadIdx.x < CGW_WG ? ws[threadIdx.x] : 0.0, red);
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      x[k] += alpha * p[k];
+      const double rn = r[k] - alpha * q[k];
+      r[k] = rn;
+      acc += rn * rn;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ws[CGW_WG + blockIdx.x] = acc;
+  } else {
+    const double beta = block_sum_256(threadIdx.x < CGW_WG ? ws[CGW_WG + threadIdx.x] : 0.0, red) / rho;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) p[k] = r[k] + beta * p[k];
+  }
+}
+__global__ __launch_bounds__(256) void cg_wide_scalars_kernel(double* __restrict__ state, const double* __restrict__ ws) {
+  __shared__ double red[4];
+  const double rho = state[0], atol = state[1];
+  if (sqrt(rho) < atol || rho == 0.0) return;
+  const double rho_new = block_sum_256(threadIdx.x < CGW_WG ? ws[CGW_WG + threadIdx.x] : 0.0, red);
+  if (threadIdx.x == 0) {
+    state[0] = rho_new;
+    state[3] += 1.0;
+  }
+}
+
 // The vector half of one Lanczos iteration j >= 1 in one workgroup:
 //   w -= beta[j-1] v_prev;  alpha[j-1] = <w, v_cur>;  w -= alpha[j-1] v_cur;  beta[j] = ||w||;  v_next = w / beta[j].
 template <bool REG>
@@ -2272,6 +2321,130 @@ __global__ __launch_bounds__(1024) void minres_update_kernel(double* __restrict_
     st[0] = istop; st[1] = itn; st[2] = oldb; st[3] = beta; st[4] = dbar; st[5] = epsln; st[6] = phibar;
     st[7] = rhs1; st[8] = rhs2; st[9] = tnorm2; st[10] = gmax; st[11] = gmin; st[12] = cs; st[13] = sn;
   }
+}
+
+// The same iteration for vectors beyond one workgroup's reach (cores of conv tensor trains), spread over MRW_WG
+// workgroups: three vector launches with their partial sums in `ws` (3 MRW_WG doubles) and one scalar launch, the only
+// one that writes the state, so that every workgroup of an iteration reads the same scalars.
+#define MRW_WG 128
+struct MinresStep {   // the scalars of one iteration that the vector updates need
+  double oldeps, delta, gamma, phi, beta_new;
+};
+__device__ __forceinline__ MinresStep minres_step(const double* __restrict__ st, double alfa, double beta_new) {
+  const double dbar = st[4], epsln = st[5], phibar = st[6], cs = st[12], sn = st[13], eps = st[17];
+  MinresStep m;
+  m.oldeps = epsln;
+  m.delta = cs * dbar + sn * alfa;
+  const double gbar = sn * dbar - cs * alfa;
+  m.gamma = fmax(hypot(gbar, beta_new), eps);
+  m.phi = (gbar / m.gamma) * phibar;
+  m.beta_new = beta_new;
+  return m;
+}
+template <int PHASE>
+__global__ __launch_bounds__(256) void minres_wide_kernel(double* __restrict__ y, double* __restrict__ r1,
+                                                           double* __restrict__ r2, double* __restrict__ v,
+                                                           double* __restrict__ w, double* __restrict__ w2,
+                                                           double* __restrict__ x, const double* __restrict__ st,
+                                                           double* __restrict__ ws, int64_t D) {
+  __shared__ double red[4];
+  if (st[0] != 0.0) return;
+  const double itn = st[1] + 1.0, oldb = st[2], beta = st[3];
+  const int64_t per = ((D + MRW_WG - 1) / MRW_WG + 1) & ~(int64_t)1;
+  const int64_t k0 = (int64_t)blockIdx.x * per, k1 = min(D, k0 + per);
+  if (PHASE == 0) {          // y <- A v - (beta / oldb) r1;  partial <v, y>
+    const double c1 = itn >= 2.0 ? beta / oldb : 0.0;
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      const double yk = itn >= 2.0 ? y[k] - c1 * r1[k] : y[k];
+      y[k] = yk;
+      acc += v[k] * yk;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+  } else if (PHASE == 1) {   // y <- y - (alfa / beta) r2;  r1 <- r2;  r2 <- y;  partial <y, y>
+    const double alfa = block_sum_256(threadIdx.x < MRW_WG ? ws[threadIdx.x] : 0.0, red);
+    const double c2 = alfa / beta;
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      const double r2k = r2[k];
+      const double yk = y[k] - c2 * r2k;
+      r1[k] = r2k;
+      r2[k] = yk;
+      acc += yk * yk;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ws[MRW_WG + blockIdx.x] = acc;
+  } else {                   // w, x and the next Lanczos vector;  partial <x, x>
+    const double alfa = block_sum_256(threadIdx.x < MRW_WG ? ws[threadIdx.x] : 0.0, red);
+    const double bnew = sqrt(block_sum_256(threadIdx.x < MRW_WG ? ws[MRW_WG + threadIdx.x] : 0.0, red));
+    const MinresStep m = minres_step(st, alfa, bnew);
+    const double denom = 1.0 / m.gamma, rb = 1.0 / bnew;
+    double acc = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      const double w1k = w2[k], w2k = w[k];
+      const double wk = (v[k] - m.oldeps * w1k - m.delta * w2k) * denom;
+      w2[k] = w2k;
+      w[k] = wk;
+      const double xk = x[k] + m.phi * wk;
+      x[k] = xk;
+      acc += xk * xk;
+      v[k] = rb * r2[k];
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ws[2 * MRW_WG + blockIdx.x] = acc;
+  }
+}
+// The scalar half of the iteration: the recurrences and stopping tests of minres_update_kernel on the three sums.
+__global__ __launch_bounds__(256) void minres_wide_scalars_kernel(double* __restrict__ st, const double* __restrict__ ws) {
+  __shared__ double red[4];
+  if (st[0] != 0.0) return;
+  const double alfa = block_sum_256(threadIdx.x < MRW_WG ? ws[threadIdx.x] : 0.0, red);
+  const double bsq = block_sum_256(threadIdx.x < MRW_WG ? ws[MRW_WG + threadIdx.x] : 0.0, red);
+  const double xsq = block_sum_256(threadIdx.x < MRW_WG ? ws[2 * MRW_WG + threadIdx.x] : 0.0, red);
+  if (threadIdx.x != 0) return;
+  const double itn = st[1] + 1.0;
+  double oldb = st[2], beta = st[3], dbar = st[4], epsln = st[5], phibar = st[6], rhs1 = st[7], rhs2 = st[8];
+  double tnorm2 = st[9], gmax = st[10], gmin = st[11], cs = st[12], sn = st[13];
+  const double beta1 = st[14], rtol = st[15], maxiter = st[16], eps = st[17];
+  oldb = beta;
+  beta = sqrt(bsq);
+  tnorm2 += alfa * alfa + oldb * oldb + beta * beta;
+  double istop = 0.0;
+  if (itn == 1.0 && beta / beta1 <= 10.0 * eps) istop = -1.0;
+  const double delta = cs * dbar + sn * alfa;
+  const double gbar = sn * dbar - cs * alfa;
+  epsln = sn * beta;
+  dbar = -cs * beta;
+  const double root = hypot(gbar, dbar);
+  const double gamma = fmax(hypot(gbar, beta), eps);
+  cs = gbar / gamma;
+  sn = beta / gamma;
+  phibar = sn * phibar;
+  const double ynorm = sqrt(xsq);
+  gmax = fmax(gmax, gamma);
+  gmin = fmin(gmin, gamma);
+  const double z = rhs1 / gamma;
+  rhs1 = rhs2 - delta * z;
+  rhs2 = -epsln * z;
+  const double Anorm = sqrt(tnorm2);
+  const double epsx = Anorm * ynorm * eps;
+  const double rnorm = phibar;
+  const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+  const double test2 = Anorm == 0.0 ? INFINITY : root / Anorm;
+  const double Acond = gmax / gmin;
+  if (istop == 0.0) {
+    const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+    if (t2 <= 1.0) istop = 2.0;
+    if (t1 <= 1.0) istop = 1.0;
+    if (itn >= maxiter) istop = 6.0;
+    if (Acond >= 0.1 / eps) istop = 4.0;
+    if (epsx >= beta1) istop = 3.0;
+    if (test2 <= rtol) istop = 2.0;
+    if (test1 <= rtol) istop = 1.0;
+  }
+  st[0] = istop; st[1] = itn; st[2] = oldb; st[3] = beta; st[4] = dbar; st[5] = epsln; st[6] = phibar;
+  st[7] = rhs1; st[8] = rhs2; st[9] = tnorm2; st[10] = gmax; st[11] = gmin; st[12] = cs; st[13] = sn;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -4499,6 +4672,44 @@ int ttk_cg_update_f64(double* x, double* r, double* p, const double* q, double* 
     hipLaunchKernelGGL(cg_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
   else
     hipLaunchKernelGGL(cg_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, q, state, D);
+  return ttk_launch_status();
+}
+
+int64_t ttk_minres_update_ws_bytes(int64_t D) {
+  if (D < 1) return TTK_EINVAL;
+  return D > 8192 ? 3 * MRW_WG * (int64_t)sizeof(double) : 0;
+}
+
+int ttk_minres_update_ws_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
+                             int64_t D, void* ws, int64_t ws_bytes, void* stream) {
+  if (!y || !r1 || !r2 || !v || !w || !w2 || !x || !state || D < 1) return TTK_EINVAL;
+  if (D <= 8192 || !ws) return ttk_minres_update_f64(y, r1, r2, v, w, w2, x, state, D, stream);
+  if (ws_bytes < ttk_minres_update_ws_bytes(D)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* p = (double*)ws;
+  hipLaunchKernelGGL(minres_wide_kernel<0>, dim3(MRW_WG), dim3(256), 0, st, y, r1, r2, v, w, w2, x, (const double*)state, p, D);
+  hipLaunchKernelGGL(minres_wide_kernel<1>, dim3(MRW_WG), dim3(256), 0, st, y, r1, r2, v, w, w2, x, (const double*)state, p, D);
+  hipLaunchKernelGGL(minres_wide_kernel<2>, dim3(MRW_WG), dim3(256), 0, st, y, r1, r2, v, w, w2, x, (const double*)state, p, D);
+  hipLaunchKernelGGL(minres_wide_scalars_kernel, dim3(1), dim3(256), 0, st, state, (const double*)p);
+  return ttk_launch_status();
+}
+
+int64_t ttk_cg_update_ws_bytes(int64_t D) {
+  if (D < 1) return TTK_EINVAL;
+  return D > 8192 ? 2 * CGW_WG * (int64_t)sizeof(double) : 0;
+}
+
+int ttk_cg_update_ws_f64(double* x, double* r, double* p, const double* q, double* state, int64_t D, void* ws,
+                         int64_t ws_bytes, void* stream) {
+  if (!x || !r || !p || !q || !state || D < 1) return TTK_EINVAL;
+  if (D <= 8192 || !ws) return ttk_cg_update_f64(x, r, p, q, state, D, stream);
+  if (ws_bytes < ttk_cg_update_ws_bytes(D)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* w = (double*)ws;
+  hipLaunchKernelGGL(cg_wide_kernel<0>, dim3(CGW_WG), dim3(256), 0, st, x, r, p, q, state, w, D);
+  hipLaunchKernelGGL(cg_wide_kernel<1>, dim3(CGW_WG), dim3(256), 0, st, x, r, p, q, state, w, D);
+  hipLaunchKernelGGL(cg_wide_kernel<2>, dim3(CGW_WG), dim3(256), 0, st, x, r, p, q, state, w, D);
+  hipLaunchKernelGGL(cg_wide_scalars_kernel, dim3(1), dim3(256), 0, st, state, (const double*)w);
   return ttk_launch_status();
 }
 

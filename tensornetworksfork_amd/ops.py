@@ -484,18 +484,42 @@ def gram_timing_read(max_n=512):
     return [buf[i] for i in range(n)]
 
 
+_cg_ws = {}
+
+
 def cg_update(x, r, p, q, state):
-    """One conjugate-gradient vector update in place (q = A p); see ttk_cg_update_f64.
-    state = [<r,r>, atol, stopped, updates done] on the device."""
+    """One conjugate-gradient vector update in place (q = A p); see ttk_cg_update_f64 / ttk_cg_update_ws_f64 (long
+    vectors are updated by many workgroups).  state = [<r,r>, atol, stopped, updates done] on the device."""
+    D = x.numel()
+    nbytes = int(_lib.lib().ttk_cg_update_ws_bytes(D))
+    if nbytes > 0:
+        ws = _cg_ws.get(x.device)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = _cg_ws[x.device] = torch.empty((nbytes + 7) // 8, dtype=F64, device=x.device)
+        rc = _lib.lib().ttk_cg_update_ws_f64(_chk(x, "x"), _chk(r, "r"), _chk(p, "p"), _chk(q, "q"), _chk(state, "state"), D,
+                                             ws.data_ptr(), nbytes, _stream(x))
+        _lib.check(rc, "ttk_cg_update_ws_f64")
+        return
     rc = _lib.lib().ttk_cg_update_f64(_chk(x, "x"), _chk(r, "r"), _chk(p, "p"), _chk(q, "q"), _chk(state, "state"),
-                                      x.numel(), _stream(x))
+                                      D, _stream(x))
     _lib.check(rc, "ttk_cg_update_f64")
 
 
 def minres_update(y, r1, r2, v, w, w2, x, state):
-    """One MINRES vector update in place (y = A v on entry); see ttk_minres_update_f64."""
+    """One MINRES vector update in place (y = A v on entry); see ttk_minres_update_f64 / ttk_minres_update_ws_f64."""
+    D = x.numel()
+    nbytes = int(_lib.lib().ttk_minres_update_ws_bytes(D))
+    if nbytes > 0:
+        ws = _cg_ws.get(x.device)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = _cg_ws[x.device] = torch.empty((nbytes + 7) // 8, dtype=F64, device=x.device)
+        rc = _lib.lib().ttk_minres_update_ws_f64(_chk(y, "y"), _chk(r1, "r1"), _chk(r2, "r2"), _chk(v, "v"), _chk(w, "w"),
+                                                 _chk(w2, "w2"), _chk(x, "x"), _chk(state, "state"), D, ws.data_ptr(), nbytes,
+                                                 _stream(x))
+        _lib.check(rc, "ttk_minres_update_ws_f64")
+        return
     rc = _lib.lib().ttk_minres_update_f64(_chk(y, "y"), _chk(r1, "r1"), _chk(r2, "r2"), _chk(v, "v"), _chk(w, "w"),
-                                          _chk(w2, "w2"), _chk(x, "x"), _chk(state, "state"), x.numel(), _stream(x))
+                                          _chk(w2, "w2"), _chk(x, "x"), _chk(state, "state"), D, _stream(x))
     _lib.check(rc, "ttk_minres_update_f64")
 
 

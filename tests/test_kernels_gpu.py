@@ -676,3 +676,50 @@ def test_rows_matvec_and_lhl(S, C, D):
     hu2 = torch.einsum('scd,sc->sd', H, u2)
     gl_ref = torch.einsum('scl,sc->sl', J, hu2)
     assert G.rel_err(ops.lhl(J.to(dev), H.to(dev), z.to(dev)), gl_ref) < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("D", [9001, 149760])
+def test_wide_krylov_updates_match_one_workgroup(D):
+    """CG and MINRES vector updates of long vectors (many workgroups, partial sums in a workspace) against the
+    one-workgroup kernels on the same data, three iterations in a row: same recurrences, sums in another order."""
+    from tensornetworksfork_amd import _lib, ops
+    dev = _dev()
+    lib = _lib.lib()
+    st_ = torch.cuda.current_stream().cuda_stream
+
+    def cg_run(wide):
+        x, r, p = (_rand((D,), k).to(dev) for k in (1, 2, 3))
+        state = torch.tensor([float((r * r).sum()), 1e-30, 0.0, 0.0], dtype=torch.float64, device=dev)
+        for it in range(3):
+            q = (3.0 * p + 0.01 * torch.roll(p, 1)).contiguous()          # a fixed SPD-like operator
+            if wide:
+                ops.cg_update(x, r, p, q, state)
+            else:
+                assert lib.ttk_cg_update_f64(x.data_ptr(), r.data_ptr(), p.data_ptr(), q.data_ptr(), state.data_ptr(), D, st_) == 0
+        return x, r, p, state
+
+    for a, b in zip(cg_run(True), cg_run(False)):
+        assert G.rel_err(a, b) < 1e-12
+
+    def minres_run(wide):
+        b = _rand((D,), 5).to(dev)
+        beta1 = b.norm()
+        y, r1, r2, v = b.clone(), b.clone(), b.clone(), (b / beta1).contiguous()
+        w, w2, x = torch.zeros_like(b), torch.zeros_like(b), torch.zeros_like(b)
+        st = torch.zeros(18, dtype=torch.float64, device=dev)
+        st[3], st[6], st[7], st[11], st[12], st[14] = beta1, beta1, beta1, 1e308, -1.0, beta1
+        st[15], st[16], st[17] = 1e-12, 50.0, 2.220446049250313e-16
+        for it in range(3):
+            y = (3.0 * v + 0.01 * torch.roll(v, 1) + 0.01 * torch.roll(v, -1)).contiguous()
+            if wide:
+                ops.minres_update(y, r1, r2, v, w, w2, x, st)
+            else:
+                assert lib.ttk_minres_update_f64(y.data_ptr(), r1.data_ptr(), r2.data_ptr(), v.data_ptr(), w.data_ptr(),
+                                                 w2.data_ptr(), x.data_ptr(), st.data_ptr(), D, st_) == 0
+        return x, v, w, w2, r1, r2, st
+
+    outs_w, outs_1 = minres_run(True), minres_run(False)
+    assert float(outs_1[-1][1].item()) == 3.0          # three iterations were counted
+    for a, b in zip(outs_w, outs_1):
+        assert G.rel_err(a, b) < 1e-11
