@@ -294,6 +294,9 @@ int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t ro
 int ttk_conv_feature_f32(const float* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream);
 int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
                       int accumulate, void* stream);
+/* 1 if ttk_env_right_dense_f64 / _mm32 take the site: right bonds up to 64 always, up to 128 when the core block of one
+ * left-bond index fits the LDS beside the waves' feature tiles (features <= 96). */
+int ttk_env_right_dense_ok(int64_t S, int rl, int p, int rr, int mm32);
 int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
                             int rr, int accumulate, void* stream);
 int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ttk_rhs_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_gemm_rows_mm32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_mm32": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_env_right_dense_ok": (_int, [_i64, _int, _int, _int, _int]),
     "ttk_rhs_feature_mm32": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_dense_scale_f64": (_int, [_c_dp, _int, _c_dp, _c_dp]),
     "ttk_chol_prepare_dense_f64": (_int, [_c_dp, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),

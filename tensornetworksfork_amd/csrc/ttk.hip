@@ -636,7 +636,11 @@ static int env_step_launch(bool left, const double* E, const double* X, const do
   if (frc != 1) return frc;
   const int K = e * p;
   int KC = round_up(K, 4);
-  const int kc_max = (48 * 1024) / (64 * 8);  // 96 rows of 64 doubles = 48 KiB
+  int kc_max = (48 * 1024) / (64 * 8);  // 96 rows of 64 doubles = 48 KiB
+  // wide bonds with many features: the per-wave operand rows take 512 (e + p) bytes, the core chunk what is left
+  const int kc_fit = (int)(((int64_t)150 * 1024 / 8 - 64 * (int64_t)(e + p)) / 64) & ~3;
+  if (kc_fit < kc_max) kc_max = kc_fit;
+  if (kc_max < 4) return TTK_EINVAL;
   if (KC > kc_max) KC = kc_max;
   const size_t lds = ((size_t)KC * 64 + 4 * 16 * (size_t)(e + p)) * sizeof(double);
   if (lds > 150 * 1024) return TTK_EINVAL;

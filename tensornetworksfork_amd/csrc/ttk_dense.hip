@@ -306,7 +306,7 @@ __device__ __forceinline__ float row16_sum(float z) {
 }
 
 template <int TPL, int LB, int ER_NA, typename TC>   // ER_NA: X tile elements per lane, 16 rows x K <= 64 ER_NA
-__global__ __launch_bounds__(512, sizeof(TC) == 4 && ER_NA <= 17 ? 4 : 2) void env_right_resident_kernel(
+__global__ __launch_bounds__(512, sizeof(TC) == 4 && ER_NA <= 17 && TPL <= 4 ? 4 : 2) void env_right_resident_kernel(
     const double* __restrict__ X, const double* __restrict__ core, double* __restrict__ out, int64_t S, int K, int rl, int rr,
     const double* __restrict__ Rv, int accumulate, int ncb, int64_t rows_xcd, int64_t rows_wg) {
   extern __shared__ double smem[];
@@ -469,7 +469,7 @@ static EnvResDims env_resident_dims(int64_t S, int rl, int K, int lb, int nt) {
   EnvResDims d;
   const int Kp = (K + 3) & ~3;
   d.lds = ((size_t)Kp * gemm_rows_bstride<TC>(nt * 16) + (size_t)8 * Kp * ER_AS) * sizeof(TC);
-  if (K > 96 || K < 4 || d.lds > 150 * 1024) d.lds = 0;
+  if (K > 96 || K < 4 || d.lds > 156 * 1024) d.lds = 0;
   d.ncb = (rl + lb - 1) / lb;
   d.rows_xcd = ((S + 7) / 8 + 63) / 64 * 64;
   // Sample ranges per XCD: the launch runs in rounds of `slots` workgroups (one per compute unit, two when the
@@ -947,7 +947,7 @@ static int gemm_rows_launch(const double* A, const double* B, double* T, int64_t
 template <typename TC>
 static int env_right_dense_launch(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
                                   int rr, int accumulate, void* stream) {
-  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 64 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
   if (!gemm_rows_allow_lds<TC>()) return TTK_ELAUNCH;
   const dim3 grid((unsigned)((S + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
@@ -957,6 +957,7 @@ static int env_right_dense_launch(const double* R, const double* X, const double
     // core block resident (the usual case: p <= 96): one launch over (XCD, column block, sample range)
     const int tpl = (rr + 15) / 16, lb = tpl == 1 ? 6 : (tpl == 2 ? 3 : (tpl == 3 ? 2 : 1));
     const EnvResDims d = env_resident_dims<TC>(S, rl, p, lb, tpl * lb);
+    if (!d.lds && rr > 64) return TTK_EINVAL;   // bonds above 64 only on the resident route (see ttk_env_right_dense_ok)
     if (d.lds) {
       const dim3 rgrid((unsigned)(8 * d.ncb * d.nsplit));
 #define ER_LAUNCH(TPL_, LB_, NA_)                                                                                        \
@@ -984,8 +985,20 @@ static int env_right_dense_launch(const double* R, const double* X, const double
         case 3:
           ER_LAUNCH_NA(3, 2)
           break;
-        default:
+        case 4:
           ER_LAUNCH_NA(4, 1)
+          break;
+        case 5:
+          ER_LAUNCH_NA(5, 1)
+          break;
+        case 6:
+          ER_LAUNCH_NA(6, 1)
+          break;
+        case 7:
+          ER_LAUNCH_NA(7, 1)
+          break;
+        default:
+          ER_LAUNCH_NA(8, 1)
           break;
       }
 #undef ER_LAUNCH_NA
@@ -1081,6 +1094,13 @@ int ttk_gemm_rows_f64(const double* A, const double* B, double* T, int64_t M, in
 int ttk_gemm_rows_mm32(const double* A, const double* B, double* T, int64_t M, int K, int N, int bmode, int rl, int rr,
                        int accumulate, void* stream) {
   return gemm_rows_launch<float>(A, B, T, M, K, N, bmode, rl, rr, accumulate, stream);
+}
+
+int ttk_env_right_dense_ok(int64_t S, int rl, int p, int rr, int mm32) {
+  if (S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > GEMM_ROWS_MAX_K) return 0;
+  if (rr <= 64) return 1;
+  const int tpl = (rr + 15) / 16;
+  return (mm32 ? env_resident_dims<float>(S, rl, p, 1, tpl).lds : env_resident_dims<double>(S, rl, p, 1, tpl).lds) ? 1 : 0;
 }
 
 int ttk_env_right_dense_f64(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,

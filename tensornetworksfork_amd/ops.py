@@ -65,7 +65,7 @@ def env_step_right(R, X, core, out=None, mm32=False):
         # the last site: out[s,l] = (X . core[:, :, 0]^T)[s,l] R[s,0], a plain row GEMM and a row scaling
         T = gemm_rows(X, core.reshape(rl, p), rl, bmode=2, mm32=mm32)
         return kr_rows(T.unsqueeze(1), R, R.new_ones((S, 1))).reshape(S, rl)
-    if DENSE_MIN_P <= p <= DENSE_MAX_P and rr <= 64:
+    if DENSE_MIN_P <= p <= DENSE_MAX_P and (rr <= 64 or _lib.lib().ttk_env_right_dense_ok(S, rl, p, rr, int(bool(mm32)))):
         fn = _lib.lib().ttk_env_right_dense_mm32 if mm32 else _lib.lib().ttk_env_right_dense_f64
         rc = fn(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)), _chk(out, "out", (S, rl)), S, rl, p, rr,
                 int(acc), _stream(R))

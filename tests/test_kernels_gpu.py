@@ -289,7 +289,8 @@ def _small_ints(shape, seed, hi=4):
 
 @gpu
 @pytest.mark.parametrize("S,C,rl,p,rr", [(300, 1, 4, 16, 4), (1000, 3, 24, 50, 24), (777, 9, 48, 65, 48), (129, 2, 1, 17, 5),
-                                         (500, 1, 7, 130, 9), (260, 2, 3, 256, 2), (64, 1, 5, 33, 1), (200, 2, 6, 40, 64)])
+                                         (500, 1, 7, 130, 9), (260, 2, 3, 256, 2), (64, 1, 5, 33, 1), (200, 2, 6, 40, 64),
+                                         (333, 9, 100, 65, 100), (150, 2, 3, 20, 128), (90, 1, 2, 96, 70)])
 def test_float32_matrix_arithmetic_of_many_feature_sites(S, C, rl, p, rr):
     """The float32 instantiations (v_mfma_f32_16x16x4_f32) of the row GEMM, the dense right-environment step and
     the features-first right-hand side: (1) on small integers every float32 product and sum is exact, so the
@@ -542,7 +543,8 @@ def test_cg_fused_matches_unfused(S, rl, p):
 
 @gpu
 @pytest.mark.parametrize("S,C,rl,p,rr", [(300, 9, 24, 50, 24), (1000, 3, 48, 65, 48), (77, 1, 5, 130, 7), (4099, 2, 9, 17, 64),
-                                         (64, 4, 16, 16, 16), (130, 9, 1, 33, 20)])
+                                         (64, 4, 16, 16, 16), (130, 9, 1, 33, 20), (333, 9, 100, 65, 100), (150, 2, 3, 20, 128),
+                                         (90, 1, 2, 96, 81), (70, 1, 2, 130, 100)])
 def test_many_feature_kernels(S, C, rl, p, rr):
     """Sites with many features (conv columns): right / left environment steps with the features
     contracted first, the plain row GEMM in its three operand layouts, and the per-sample

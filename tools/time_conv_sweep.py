@@ -7,6 +7,8 @@ from tensornetworksfork_amd.tensor.bregman import XEAutogradBregman
 cfg = sys.argv[1] if len(sys.argv) > 1 else "mnist"
 # mnist: image_convolution_lanczos_MNIST.py shapes, fp64; cifar: CIFAR_lanczos_swipe.py:35-38 shapes, float32 default dtype
 S, R_, P_, PX_, DT = (54000, 24, 50, 17, torch.float64) if cfg == "mnist" else (50000, 48, 65, 49, torch.float32)
+if len(sys.argv) > 2:      # bond override (image_convolution_lanczos_CIFAR10.py itself uses 100)
+    R_ = int(sys.argv[2])
 torch.set_default_dtype(DT)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -18,13 +20,15 @@ times = []
 def cb(NS, node):
     torch.cuda.synchronize()
     times.append((node.name, time.perf_counter()))
+with torch.inference_mode():      # the scripts scale the loss by the spread of the first predictions
+    wgt = 1.0 / layer(x[:64]).std().item()
 torch.manual_seed(1)
 warm = TensorConvolutionTrainLayer(3, R_, P_, PX_, output_shape=9, convolution_bond=-1).to(dev).tensor_network
-warm.lanczos_swipe(x, y, XEAutogradBregman(), batch_size=512, num_swipes=1, max_iter=12)   # warm-up on another model
+warm.lanczos_swipe(x, y, XEAutogradBregman(w=wgt), batch_size=512, num_swipes=1, max_iter=12)   # warm-up on another model
 times.clear()
 torch.manual_seed(1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-tn.lanczos_swipe(x, y, XEAutogradBregman(), batch_size=512, num_swipes=1, max_iter=12, block_callback=cb)
+tn.lanczos_swipe(x, y, XEAutogradBregman(w=wgt), batch_size=512, num_swipes=1, max_iter=12, block_callback=cb)
 prev = t0
 for name, t in times:
     print(name, "ms", round((t - prev) * 1e3, 2)); prev = t
