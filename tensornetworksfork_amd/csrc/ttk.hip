@@ -2092,7 +2092,7 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict_
 //                                       many-feature site in one kernel instead of three (L read once, not twice).
 // A workgroup stages NS whole samples (NS C D doubles, one contiguous range) in LDS; LPR lanes share a row in the
 // first product, the Hessian product is one thread per (sample, output), the last product one thread per column.
-template <int MODE, int LPR>
+template <int MODE, int LPR, int NW = 2>   // NW: 64-column groups of a row (D <= 64 NW)
 __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict__ J, const double* __restrict__ H,
                                                         const double* __restrict__ x, double* __restrict__ out, int64_t S,
                                                         int C, int D, int NS) {
@@ -2105,7 +2105,10 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
   const int tid = threadIdx.x, sub = tid % LPR, grp = tid / LPR;
   constexpr int NGRP = 256 / LPR;
   const int64_t nchunks = (S + NS - 1) / NS;
-  double q0 = 0.0, q1 = 0.0;               // MODE 0: columns tid % 64 and 64 + tid % 64, rows tid / 64 mod 4
+  constexpr int NU = NW == 2 ? 4 : 8;      // steps of LPR entries per row in the first product (D <= NU LPR)
+  double q[NW];                            // MODE 0: columns tid % 64 + 64 w, rows tid / 64 mod 4
+#pragma unroll
+  for (int w = 0; w < NW; ++w) q[w] = 0.0;
   // A chunk travels memory -> registers -> LDS; the registers are filled for chunk c+1 before chunk c is worked
   // on, so the loads (unconditional, clamped) are in flight during the three phases.
   double tj[16], th[8], tx[16];
@@ -2145,16 +2148,16 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     }
     __syncthreads();
     if (ch + gridDim.x < nchunks) fetch(ch + gridDim.x);
-    // D <= 4 LPR: four predicated steps per row, two rows per pass, all LDS reads of a pass issued together
+    // D <= NU LPR: NU predicated steps per row, two rows per pass, all LDS reads of a pass issued together
     for (int row = grp; row < rows; row += 2 * NGRP) {
       const int rowb = min(row + NGRP, rows - 1);
       const double* ja = Jc + row * D;
       const double* jb = Jc + rowb * D;
       const double* xa = MODE == 0 ? xs : xs + (row / C) * D;
       const double* xb = MODE == 0 ? xs : xs + (rowb / C) * D;
-      double pa[4], pb[4], va[4], vb[4];
+      double pa[NU], pb[NU], va[NU], vb[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int d = min(sub + u * LPR, D - 1);
         pa[u] = ja[d];
         pb[u] = jb[d];
@@ -2163,7 +2166,7 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
       }
       double acca = 0.0, accb = 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const bool ok = sub + u * LPR < D;
         acca += ok ? pa[u] * va[u] : 0.0;
         accb += ok ? pb[u] * vb[u] : 0.0;
@@ -2189,27 +2192,32 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     __syncthreads();
     if (MODE == 0) {
       const int d = tid & 63, g4 = tid >> 6;
-      const int da = min(d, D - 1), db = min(d + 64, D - 1);
-      const bool oka = d < D, okb = d + 64 < D;
-      int row = g4;
-      for (; row + 12 < rows; row += 16) {   // four rows per pass
-        double h[4], ja[4], jb[4];
+      int dc[NW];
+      bool okc[NW];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          h[u] = hb[row + 4 * u];
-          ja[u] = Jc[(row + 4 * u) * D + da];
-          jb[u] = okb ? Jc[(row + 4 * u) * D + db] : 0.0;
+      for (int w = 0; w < NW; ++w) {
+        dc[w] = min(d + 64 * w, D - 1);
+        okc[w] = d + 64 * w < D;
+      }
+      int row = g4;
+      for (; row + 4 < rows; row += 8) {   // two rows per pass
+        const double h0 = hb[row], h1 = hb[row + 4];
+        double j0[NW], j1[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          j0[w] = Jc[row * D + dc[w]];
+          j1[w] = Jc[(row + 4) * D + dc[w]];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          q0 += oka ? ja[u] * h[u] : 0.0;
-          q1 += jb[u] * h[u];
+        for (int w = 0; w < NW; ++w) {
+          q[w] += okc[w] ? j0[w] * h0 : 0.0;
+          q[w] += okc[w] ? j1[w] * h1 : 0.0;
         }
       }
       for (; row < rows; row += 4) {
         const double h = hb[row];
-        if (oka) q0 += Jc[row * D + da] * h;
-        if (okb) q1 += Jc[row * D + db] * h;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) q[w] += okc[w] ? Jc[row * D + dc[w]] * h : 0.0;
       }
     } else {
       for (int t = tid; t < ns * D; t += 256) {
@@ -2222,12 +2230,12 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     __syncthreads();
   }
   if (MODE == 0) {   // the four row groups of each column, fixed order
-    double* red = sm;   // [4][128]
-    red[(tid >> 6) * 128 + (tid & 63)] = q0;
-    red[(tid >> 6) * 128 + 64 + (tid & 63)] = q1;
+    double* red = sm;   // [4][64 NW]
+#pragma unroll
+    for (int w = 0; w < NW; ++w) red[(tid >> 6) * (64 * NW) + 64 * w + (tid & 63)] = q[w];
     __syncthreads();
     for (int d = tid; d < D; d += 256)
-      out[(int64_t)blockIdx.x * D + d] = (red[d] + red[128 + d]) + (red[256 + d] + red[384 + d]);
+      out[(int64_t)blockIdx.x * D + d] = (red[d] + red[64 * NW + d]) + (red[128 * NW + d] + red[192 * NW + d]);
   }
 }
 
@@ -4745,7 +4753,7 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
 
 // samples per LDS chunk and grid of rows_hjv_kernel
 static bool rows_hjv_dims(int64_t S, int C, int D, int mode, int* NS, int* grid, size_t* lds) {
-  if (S < 1 || C < 1 || C > 32 || D < 1 || D > 128 || (int64_t)C * D > 4096) return false;
+  if (S < 1 || C < 1 || C > 32 || D < 1 || D > (mode == 0 ? 512 : 128) || (int64_t)C * D > 4096) return false;
   int ns = 4096 / (C * D);
   if (ns > 2048 / (C * C)) ns = 2048 / (C * C);   // the Hessians of the chunk sit in LDS too
   if (ns < 1) ns = 1;
@@ -4754,7 +4762,7 @@ static bool rows_hjv_dims(int64_t S, int C, int D, int mode, int* NS, int* grid,
   *NS = ns;
   *grid = (int)min((int64_t)1024, nchunks);
   size_t doubles = (size_t)ns * C * D + 2 * (size_t)ns * C + (size_t)ns * C * C + (mode == 0 ? (size_t)D : (size_t)ns * D);
-  if (doubles < 512) doubles = 512;   // the final reduction of mode 0 reuses the buffer as [4][128]
+  if (doubles < 2048) doubles = 2048;   // the final reduction of mode 0 reuses the buffer as [4][64 NW]
   *lds = doubles * sizeof(double);
   return true;
 }
@@ -4765,8 +4773,10 @@ static void rows_hjv_launch(int mode, const double* J, const double* H, const do
     fn = mode ? rows_hjv_kernel<1, 8> : rows_hjv_kernel<0, 8>;
   else if (D <= 64)
     fn = mode ? rows_hjv_kernel<1, 16> : rows_hjv_kernel<0, 16>;
-  else
+  else if (D <= 128)
     fn = mode ? rows_hjv_kernel<1, 32> : rows_hjv_kernel<0, 32>;
+  else
+    fn = rows_hjv_kernel<0, 64, 8>;   // explicit rows of a filter node with a convolution bond (4 x 17 x 4 = 272 entries)
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, st, J, H, x, out, S, C, D, NS);
 }
 

@@ -194,9 +194,7 @@ class LocalProblem:
     def jv(self, v):
         """u[s,c] = J v."""
         if self.J is not None:
-            if self.D <= DENSE_ROWS_KERNEL_MAX_D:
-                return ops.rows_dot(self.J.contiguous(), v.reshape(self.D).contiguous())
-            return (self._jt() * v.reshape(self.D, 1)).sum(dim=0).reshape(self.S, self.C)
+            return ops.rows_dot(self.J.contiguous(), v.reshape(self.D).contiguous())
         v = v.reshape(self.shape)
         u = None
         tmp = {}
@@ -222,8 +220,7 @@ class LocalProblem:
             L, X, R = self.terms[0]
             return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
-        if self.J is not None and self.D <= DENSE_ROWS_KERNEL_MAX_D and H.shape[1] == self.C \
-                and ops.rows_matvec_supported(self.S, self.C, self.D):
+        if self.J is not None and H.shape[1] == self.C and ops.rows_matvec_supported(self.S, self.C, self.D):
             # explicit rows of a narrow node (conv filter): the whole operator in one pass over the rows
             J = self.J.contiguous()
             return lambda v: ops.rows_matvec(J, H, v.reshape(self.D).contiguous()).reshape(self.shape)

@@ -193,7 +193,7 @@ def rows_dot(J, v):
 
 
 def rows_matvec_supported(S, C, D):
-    return D <= 128 and C <= 32 and C * D <= 4096
+    return D <= 512 and C <= 32 and C * D <= 4096
 
 
 def rows_matvec(J, H, v):

@@ -617,7 +617,8 @@ def test_gemm_tn_and_dense_cholesky(n, D1, D2):
 
 
 @gpu
-@pytest.mark.parametrize("S,C,D", [(1000, 9, 49), (54001, 9, 17), (777, 1, 5), (300, 3, 33), (129, 2, 128), (64, 10, 1)])
+@pytest.mark.parametrize("S,C,D", [(1000, 9, 49), (54001, 9, 17), (777, 1, 5), (300, 3, 33), (129, 2, 128), (64, 10, 1),
+                                   (500, 9, 272), (100, 2, 1000)])
 def test_rows_dot(S, C, D):
     """J v for explicit rows (filter nodes of a conv tensor train) against a float64 CPU product."""
     from tensornetworksfork_amd import ops
@@ -660,7 +661,7 @@ def test_lanczos_update_wide(D):
 
 @gpu
 @pytest.mark.parametrize("S,C,D", [(1000, 9, 49), (20011, 9, 17), (777, 1, 5), (300, 3, 33), (129, 2, 128), (64, 10, 1),
-                                   (513, 32, 128)])
+                                   (513, 32, 128), (2000, 9, 272), (333, 8, 512), (257, 3, 129)])
 def test_rows_matvec_and_lhl(S, C, D):
     """The one-pass operators on per-sample blocks of rows, against float64 CPU products: J^T H J v for a narrow
     node, and GL = L^T H (L z) per sample; non-symmetric Hessians pin the orientation of the Hessian product."""
@@ -674,6 +675,8 @@ def test_rows_matvec_and_lhl(S, C, D):
     q = ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev))
     assert G.rel_err(q, q_ref) < 1e-12
     assert torch.equal(q, ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev)))      # fixed summation order
+    if D > 128:      # the per-sample form serves left environments, whose bond stays below that
+        return
     u2 = torch.einsum('scl,sl->sc', J, z)
     hu2 = torch.einsum('scd,sc->sd', H, u2)
     gl_ref = torch.einsum('scl,sc->sl', J, hu2)
