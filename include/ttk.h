@@ -259,6 +259,10 @@ int ttk_rows_dot_f64(const double* J, const double* v, double* out, int64_t rows
 int64_t ttk_rows_matvec_ws_bytes(int64_t S, int C, int D);
 int ttk_rows_matvec_f64(const double* J, const double* H, const double* v, double* q, int64_t S, int C, int D, void* ws,
                         int64_t ws_bytes, void* stream);
+/* b (D) = J^T g = sum_{s,c} g[s,c] J[s,c,:] for explicit rows (get_b, tensor/network.py:258-291, of a narrow node); same
+ * kernel, extents and workspace as ttk_rows_matvec_f64. */
+int ttk_rows_rhs_f64(const double* J, const double* g, double* b, int64_t S, int C, int D, void* ws, int64_t ws_bytes,
+                     void* stream);
 /* GL (S, rl) = L_s^T H_s (L_s z_s) per sample, L (S, C, rl <= 128), z (S, rl): the prediction from the contracted
  * environments, the Hessian product and the g.L factor of the right-hand side (the middle of the two einsums at
  * tensor/network.py:788-789 for a site whose features were contracted first) in one kernel. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ttk_rows_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _c_dp]),
     "ttk_rows_matvec_ws_bytes": (_i64, [_i64, _int, _int]),
     "ttk_rows_matvec_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_rows_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_lhl_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
 }
 

@@ -2120,8 +2120,13 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     const double* sh = H + s0 * C * C;
 #pragma unroll
     for (int u = 0; u < 16; ++u) tj[u] = sj[min(tid + 256 * u, n - 1)];
+    if (MODE != 2) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) th[u] = sh[min(tid + 256 * u, nh - 1)];
+      for (int u = 0; u < 8; ++u) th[u] = sh[min(tid + 256 * u, nh - 1)];
+    } else {   // MODE 2: x = g (S, C), the weights of the rows; no Hessian, no first product
+#pragma unroll
+      for (int u = 0; u < 8; ++u) th[u] = x[s0 * C + min(tid + 256 * u, ns * C - 1)];
+    }
     if (MODE == 1) {
       const double* sx = x + s0 * D;
 #pragma unroll
@@ -2138,9 +2143,15 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       if (tid + 256 * u < n) Jc[tid + 256 * u] = tj[u];
+    if (MODE != 2) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (tid + 256 * u < rows * C) Hc[tid + 256 * u] = th[u];
+      for (int u = 0; u < 8; ++u)
+        if (tid + 256 * u < rows * C) Hc[tid + 256 * u] = th[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tid + 256 * u < rows) hb[tid + 256 * u] = th[u];
+    }
     if (MODE == 1) {
 #pragma unroll
       for (int u = 0; u < 16; ++u)
@@ -2149,6 +2160,7 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     __syncthreads();
     if (ch + gridDim.x < nchunks) fetch(ch + gridDim.x);
     // D <= NU LPR: NU predicated steps per row, two rows per pass, all LDS reads of a pass issued together
+    if (MODE != 2)
     for (int row = grp; row < rows; row += 2 * NGRP) {
       const int rowb = min(row + NGRP, rows - 1);
       const double* ja = Jc + row * D;
@@ -2181,16 +2193,18 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
         if (row + NGRP < rows) ub[row + NGRP] = accb;
       }
     }
-    __syncthreads();
-    for (int t = tid; t < rows; t += 256) {
-      const int sl = t / C, d = t - sl * C;
-      const double* Hs = Hc + sl * C * C;
-      double acc = 0.0;
-      for (int c = 0; c < C; ++c) acc += Hs[c * C + d] * ub[sl * C + c];
-      hb[t] = acc;
+    if (MODE != 2) {
+      __syncthreads();
+      for (int t = tid; t < rows; t += 256) {
+        const int sl = t / C, d = t - sl * C;
+        const double* Hs = Hc + sl * C * C;
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) acc += Hs[c * C + d] * ub[sl * C + c];
+        hb[t] = acc;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (MODE == 0) {
+    if (MODE != 1) {
       const int d = tid & 63, g4 = tid >> 6;
       int dc[NW];
       bool okc[NW];
@@ -2229,7 +2243,7 @@ __global__ __launch_bounds__(256) void rows_hjv_kernel(const double* __restrict_
     }
     __syncthreads();
   }
-  if (MODE == 0) {   // the four row groups of each column, fixed order
+  if (MODE != 1) {   // the four row groups of each column, fixed order
     double* red = sm;   // [4][64 NW]
 #pragma unroll
     for (int w = 0; w < NW; ++w) red[(tid >> 6) * (64 * NW) + 64 * w + (tid & 63)] = q[w];
@@ -4753,7 +4767,7 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
 
 // samples per LDS chunk and grid of rows_hjv_kernel
 static bool rows_hjv_dims(int64_t S, int C, int D, int mode, int* NS, int* grid, size_t* lds) {
-  if (S < 1 || C < 1 || C > 32 || D < 1 || D > (mode == 0 ? 512 : 128) || (int64_t)C * D > 4096) return false;
+  if (S < 1 || C < 1 || C > 32 || D < 1 || D > (mode != 1 ? 512 : 128) || (int64_t)C * D > 4096) return false;
   int ns = 4096 / (C * D);
   if (ns > 2048 / (C * C)) ns = 2048 / (C * C);   // the Hessians of the chunk sit in LDS too
   if (ns < 1) ns = 1;
@@ -4770,13 +4784,13 @@ static void rows_hjv_launch(int mode, const double* J, const double* H, const do
                             int D, int NS, int grid, size_t lds, hipStream_t st) {
   void (*fn)(const double*, const double*, const double*, double*, int64_t, int, int, int);
   if (D <= 32)
-    fn = mode ? rows_hjv_kernel<1, 8> : rows_hjv_kernel<0, 8>;
+    fn = mode == 2 ? rows_hjv_kernel<2, 8> : (mode ? rows_hjv_kernel<1, 8> : rows_hjv_kernel<0, 8>);
   else if (D <= 64)
-    fn = mode ? rows_hjv_kernel<1, 16> : rows_hjv_kernel<0, 16>;
+    fn = mode == 2 ? rows_hjv_kernel<2, 16> : (mode ? rows_hjv_kernel<1, 16> : rows_hjv_kernel<0, 16>);
   else if (D <= 128)
-    fn = mode ? rows_hjv_kernel<1, 32> : rows_hjv_kernel<0, 32>;
-  else
-    fn = rows_hjv_kernel<0, 64, 8>;   // explicit rows of a filter node with a convolution bond (4 x 17 x 4 = 272 entries)
+    fn = mode == 2 ? rows_hjv_kernel<2, 32> : (mode ? rows_hjv_kernel<1, 32> : rows_hjv_kernel<0, 32>);
+  else   // explicit rows of a filter node with a convolution bond (4 x 17 x 4 = 272 entries)
+    fn = mode == 2 ? rows_hjv_kernel<2, 64, 8> : rows_hjv_kernel<0, 64, 8>;
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, st, J, H, x, out, S, C, D, NS);
 }
 
@@ -4800,6 +4814,22 @@ int ttk_rows_matvec_f64(const double* J, const double* H, const double* v, doubl
   if (rc != TTK_OK) return rc;
   hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)ws, grid,
                      (int64_t)D, (int64_t)D, q, 0);
+  return ttk_launch_status();
+}
+
+int ttk_rows_rhs_f64(const double* J, const double* g, double* b, int64_t S, int C, int D, void* ws, int64_t ws_bytes,
+                     void* stream) {
+  if (!J || !g || !b || !ws) return TTK_EINVAL;
+  int NS, grid;
+  size_t lds;
+  if (!rows_hjv_dims(S, C, D, 0, &NS, &grid, &lds)) return TTK_EINVAL;
+  if (ws_bytes < (int64_t)grid * D * (int64_t)sizeof(double)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  rows_hjv_launch(2, J, J, g, (double*)ws, S, C, D, NS, grid, lds, st);
+  int rc = ttk_launch_status();
+  if (rc != TTK_OK) return rc;
+  hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)ws, grid,
+                     (int64_t)D, (int64_t)D, b, 0);
   return ttk_launch_status();
 }
 

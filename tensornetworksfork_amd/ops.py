@@ -568,6 +568,24 @@ def rows_matvec(J, H, v):
     return q
 
 
+def rows_rhs(J, g):
+    """b (D,) = J^T g for explicit rows J (S, C, D) and weights g (S, C), one pass over J."""
+    S, C, D = J.shape
+    nbytes = int(_lib.lib().ttk_rows_matvec_ws_bytes(S, C, D))
+    if nbytes <= 0:
+        raise _lib.TTKError("ttk_rows_matvec_ws_bytes: extents not supported")
+    key = (J.device, nbytes)
+    ws = _rowsmv_ws.get(key)
+    if ws is None:
+        _rowsmv_ws.clear()
+        ws = _rowsmv_ws[key] = torch.empty((nbytes + 7) // 8, dtype=F64, device=J.device)
+    b = torch.empty((D,), dtype=F64, device=J.device)
+    rc = _lib.lib().ttk_rows_rhs_f64(_chk(J, "J"), _chk(g, "g", (S, C)), b.data_ptr(), S, C, D, ws.data_ptr(), nbytes,
+                                     _stream(J))
+    _lib.check(rc, "ttk_rows_rhs_f64")
+    return b
+
+
 def lhl(L, H, z):
     """GL (S, rl) = L_s^T H_s (L_s z_s) per sample: predict + Hessian product + g.L in one kernel."""
     S, C, rl = L.shape

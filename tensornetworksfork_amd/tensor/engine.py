@@ -171,7 +171,9 @@ class LocalProblem:
                 # explicit rows are a Khatri-Rao term with the rows as left factor and no other factor
                 one = _ones_col(self.S, g.device)
                 return ops.rhs(self.J.contiguous(), one, one, g.reshape(self.S, self.C).contiguous()).reshape(self.shape)
-            # wide rows: element-wise product + row sums (the library's tall-skinny matrix-vector kernels are slow)
+            if ops.rows_matvec_supported(self.S, self.C, self.D):
+                return ops.rows_rhs(self.J.contiguous(), g.reshape(self.S, self.C).contiguous()).reshape(self.shape)
+            # wider rows still: element-wise product + row sums (the library's tall-skinny matrix-vector kernels are slow)
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
         for (L, X, R) in self.terms:

@@ -202,6 +202,10 @@ def rows_matvec(J, H, v):
     return torch.einsum('scd,sc->d', J, hu)
 
 
+def rows_rhs(J, g):
+    return torch.einsum('scd,sc->d', J, g)
+
+
 def lhl(L, H, z):
     u = torch.einsum('scl,sl->sc', L, z)
     hu = torch.einsum('scd,sc->sd', H, u)
@@ -299,7 +303,7 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rows_matvec_supported rows_matvec lhl rhs_supported rhs_feature").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature").split()
 
 
 def install(monkeypatch):

@@ -675,6 +675,8 @@ def test_rows_matvec_and_lhl(S, C, D):
     q = ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev))
     assert G.rel_err(q, q_ref) < 1e-12
     assert torch.equal(q, ops.rows_matvec(J.to(dev), H.to(dev), v.to(dev)))      # fixed summation order
+    gw = _rand((S, C), 95)
+    assert G.rel_err(ops.rows_rhs(J.to(dev), gw.to(dev)), torch.einsum('scd,sc->d', J, gw)) < 1e-12
     if D > 128:      # the per-sample form serves left environments, whose bond stays below that
         return
     u2 = torch.einsum('scl,sl->sc', J, z)
