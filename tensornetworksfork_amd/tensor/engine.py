@@ -123,6 +123,11 @@ def _ones_col(S, device):
     return _ONES[key]
 
 
+def _tkey(t):
+    """The same memory seen through two view objects is one operand."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
 def _rhs_features_first(rl, p, rr):
     """Whether J^T u of a Khatri-Rao term goes to the features-first kernel.  The three-factor kernel streams
     every slab of samples once per 4 x 96 output columns ("passes"); the features-first one stages a chunk once
@@ -176,11 +181,23 @@ class LocalProblem:
             # wider rows still: element-wise product + row sums (the library's tall-skinny matrix-vector kernels are slow)
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
         out = None
+        # terms of a convolution bond share their left environments (L_a for every b): g . L once per L
+        shared = {}
+        if self.C > 1 and len(self.terms) > 1:
+            for (L, _, _) in self.terms:
+                shared[_tkey(L)] = shared.get(_tkey(L), 0) + 1
+        gls = {}
+
+        def gl_of(L):
+            if _tkey(L) not in gls:
+                gls[_tkey(L)] = ops.gl(g, L)
+            return gls[_tkey(L)]
         for (L, X, R) in self.terms:
             if _rhs_features_first(L.shape[2], X.shape[1], R.shape[1]):
                 # many features and a wide output: the GEMM over the samples with the features as rows
-                out = ops.rhs_feature(L, X, R, g, mm32=self.mm32) if out is None else \
-                    ops.rhs_feature(L, X, R, g, out=out, mm32=self.mm32)
+                GLs = gl_of(L) if shared.get(_tkey(L), 0) > 1 else None
+                out = ops.rhs_feature(L, X, R, g, mm32=self.mm32, GL=GLs) if out is None else \
+                    ops.rhs_feature(L, X, R, g, out=out, mm32=self.mm32, GL=GLs)
             elif not ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
                 # a sample row too wide for the right-hand-side kernel's LDS chunk: features last,
                 # b[l,p,r] = sum_s X[s,p] (GL[s,l] R[s,r]),  GL = g . L, as one transposed product over the samples
@@ -189,6 +206,10 @@ class LocalProblem:
                 W = ops.kr_rows(GL.unsqueeze(1), _ones_col(S, g.device), R).reshape(S, rl * rr)   # GL[s,l] R[s,r]
                 bt = ops.gemm_tn(X, W).reshape(X.shape[1], rl, rr).permute(1, 0, 2)
                 out = bt.contiguous() if out is None else out.add_(bt)
+            elif shared.get(_tkey(L), 0) > 1:
+                GL1 = gl_of(L).unsqueeze(1)                                              # (S, 1, rl): one "output"
+                one = _ones_col(L.shape[0], g.device)
+                out = ops.rhs(GL1, X, R, one) if out is None else ops.rhs(GL1, X, R, one, out=out)
             else:
                 out = ops.rhs(L, X, R, g) if out is None else ops.rhs(L, X, R, g, out=out)
         return out
@@ -200,18 +221,24 @@ class LocalProblem:
         v = v.reshape(self.shape)
         u = None
         tmp = {}
+        zs = {}
         for (L, X, R) in self.terms:
             if TWO_STAGE_MIN_P <= X.shape[1] <= TWO_STAGE_MAX_P:
                 # many features: contract them first, T[s,(l,r)] = X[s,:] . v[l,:,r] (one GEMM shared by the
-                # C outputs of a sample, never stored), then the two environments: C*p/(C+p) times fewer FLOPs
-                z = ops.env_step_right(R, X, v.contiguous(), mm32=self.mm32)             # (S, rl)
-                u = ops.predict(L, z) if u is None else ops.predict(L, z, out=u)         # (S, C)
+                # C outputs of a sample, never stored), then the two environments: C*p/(C+p) times fewer FLOPs;
+                # terms that share the left environment (a convolution bond) are summed before it is applied
+                if _tkey(L) in zs:
+                    ops.env_step_right(R, X, v.contiguous(), out=zs[_tkey(L)][1], mm32=self.mm32)
+                else:
+                    zs[_tkey(L)] = (L, ops.env_step_right(R, X, v.contiguous(), mm32=self.mm32))   # (S, rl)
                 continue
             key = id(R)                  # terms that share R share one environment-step buffer
             if key in tmp:
                 ops.env_step_left(L, X, v, out=tmp[key][0])
             else:
                 tmp[key] = (ops.env_step_left(L, X, v), R)
+        for L, z in zs.values():
+            u = ops.predict(L, z) if u is None else ops.predict(L, z, out=u)             # (S, C)
         for t, R in tmp.values():
             u = ops.predict(t, R) if u is None else ops.predict(t, R, out=u)
         return u
