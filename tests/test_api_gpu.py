@@ -315,3 +315,38 @@ def test_default_train_script_flow(capsys):
     # what the callback saw on the training set is the model after that update: the last entry equals a fresh evaluation
     final = torch.sqrt(torch.mean((layer(xt) - yt) ** 2)).item()
     assert abs(final - seen[-1][0]) <= 1e-12 * max(1.0, final)
+
+
+@gpu
+def test_callback_exception_leaves_the_sweep_reusable():
+    """An exception raised by a user callback travels out of accumulating_swipe; the network (two-stream state,
+    speculative front, pending pivot check) is left in a state from which the next sweep runs normally, also under
+    torch.inference_mode as the conv scripts use it for predictions."""
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    torch.set_default_dtype(torch.float64)
+    g = torch.Generator().manual_seed(2)
+    x = [(torch.rand(800, 3, generator=g) * 2 - 1).to(DEV) for _ in range(4)]
+    y = torch.randn(800, 1, generator=g).to(DEV)
+    layer = TensorTrainLayer(4, 5, 3, output_shape=1, constrict_bond=True, seed=3).to(DEV)
+    tn = layer.tensor_network
+    calls = []
+
+    def boom(NS, node):
+        calls.append(node.name)
+        if len(calls) == 2:
+            raise RuntimeError("stop here")
+
+    with pytest.raises(RuntimeError, match="stop here"):
+        tn.accumulating_swipe(x, y, SquareBregFunction(), batch_size=256, method="ridge_cholesky", eps=1.0,
+                              orthonormalize=True, block_callback=boom)
+    assert tn._streams is None and not tn._in_user
+    losses = []
+    with torch.inference_mode():
+        before = layer(x).clone()
+    ok = tn.accumulating_swipe(x, y, SquareBregFunction(), batch_size=256, method="ridge_cholesky", eps=1.0,
+                               orthonormalize=True, loss_callback=lambda NS, n, l: losses.append(l))
+    assert ok is True and len(losses) == 7 and losses[-1] < losses[0]     # 4 updates forward, 3 back
+    with torch.inference_mode():
+        after = layer(x)
+    assert not torch.equal(before, after)
