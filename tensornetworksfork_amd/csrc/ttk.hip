@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256) void gram_expand_kernel(const double* __restri
 #define RHS_QX 2
 #define RHS_QR 8
 struct RhsDims {
-  int mt, ntl, bn, nblocks, passes, nslabs, CH, W;
+  int mt, ntl, nv, bn, nblocks, passes, nslabs, CH, W;
   int64_t slab_len;
 };
 
@@ -1207,7 +1207,10 @@ static RhsDims rhs_dims(int64_t S, int C, int rl, int p, int rr) {
   RhsDims d;
   d.mt = (rl + 15) / 16;
   d.ntl = (p * rr + 15) / 16;
-  d.bn = (d.ntl + 2) / 3;
+  // a wave owns 2 x 3 output tiles; with a single row tile (left bond <= 16) 1 x 3 while that keeps the four waves
+  // to one pass, else 1 x 6, so that no empty tile is multiplied
+  d.nv = d.mt == 1 && d.ntl > 12 ? 6 : 3;
+  d.bn = (d.ntl + d.nv - 1) / d.nv;
   d.nblocks = ((d.mt + 1) / 2) * d.bn;
   d.passes = (d.nblocks + 3) / 4;
   const int wd = rl + p + rr + 1;
@@ -1257,6 +1260,7 @@ __device__ __forceinline__ void rhs_slot_dst(int tid, int width, int W, int col0
   }
 }
 
+template <int MU, int NV>   // output tiles of a wave: MU row tiles x NV column tiles
 __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ A, const double* __restrict__ X,
                                                       const double* __restrict__ R, const double* __restrict__ gx,
                                                       int64_t S, int rl, int p, int rr, RhsDims rd,
@@ -1303,15 +1307,15 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
     const bool active = blk < rd.nblocks;
     const int tm = active ? blk / rd.bn : 0, tn = active ? blk - tm * rd.bn : 0;
     (void)bm;
-    int oA[2], oX[3], oR[3];
+    int oA[MU], oX[NV], oR[NV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int l = (tm * 2 + u) * 16 + i;
+    for (int u = 0; u < MU; ++u) {
+      const int l = (tm * MU + u) * 16 + i;
       oA[u] = l < rl ? l : W - 1;
     }
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int n = (tn * 3 + v) * 16 + i;
+    for (int v = 0; v < NV; ++v) {
+      const int n = (tn * NV + v) * 16 + i;
       if (n < N) {
         const int pn = n / rr;
         oX[v] = rl + pn;
@@ -1320,11 +1324,11 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
         oX[v] = oR[v] = W - 1;
       }
     }
-    d4 acc[2][3];
+    d4 acc[MU][NV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < MU; ++u)
 #pragma unroll
-      for (int v = 0; v < 3; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int v = 0; v < NV; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
     if (s_begin < s_end) fetch(s_begin);
     for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
       const int nvalid = (int)min((int64_t)CH, s_end - c0);
@@ -1348,27 +1352,27 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
 #pragma unroll 2
         for (int ks = 0; ks < steps; ++ks) {
           const double* row = smem + (ks * 4 + kq) * W;
-          double av[2], bv[3];
+          double av[MU], bv[NV];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) av[u] = row[oA[u]];
+          for (int u = 0; u < MU; ++u) av[u] = row[oA[u]];
 #pragma unroll
-          for (int v = 0; v < 3; ++v) bv[v] = row[oX[v]] * row[oR[v]];
+          for (int v = 0; v < NV; ++v) bv[v] = row[oX[v]] * row[oR[v]];
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < MU; ++u)
 #pragma unroll
-            for (int v = 0; v < 3; ++v) acc[u][v] = MFMA_F64(av[u], bv[v], acc[u][v]);
+            for (int v = 0; v < NV; ++v) acc[u][v] = MFMA_F64(av[u], bv[v], acc[u][v]);
         }
       }
     }
     if (active) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < MU; ++u)
 #pragma unroll
-        for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int l = (tm * 2 + u) * 16 + kq + 4 * t;
-            const int n = (tn * 3 + v) * 16 + i;
+            const int l = (tm * MU + u) * 16 + kq + 4 * t;
+            const int n = (tn * NV + v) * 16 + i;
             if (l < rl && n < N) dst[(int64_t)l * N + n] = acc[u][v][t];
           }
     }
@@ -4542,7 +4546,12 @@ static int rhs_run(const double* L, const double* X, const double* R, const doub
     gx = nullptr;
   }
   const size_t lds = (size_t)d.CH * d.W * sizeof(double);
-  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
+  if (d.mt == 1 && d.nv == 3)
+    hipLaunchKernelGGL((rhs_kernel<1, 3>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
+  else if (d.mt == 1)
+    hipLaunchKernelGGL((rhs_kernel<1, 6>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
+  else
+    hipLaunchKernelGGL((rhs_kernel<2, 3>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.nslabs > 32)

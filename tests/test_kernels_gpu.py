@@ -29,6 +29,8 @@ SHAPES = [  # S, C, rl, p, rr
     # one output, square bonds of 16 / 32, at most 8 features: the one-pass matrix-free product (ragged slabs,
     # a single partial chunk, one feature, the widest core)
     (3001, 1, 16, 5, 16), (1000, 1, 32, 8, 32), (9, 1, 16, 1, 16), (16411, 1, 32, 3, 32), (33, 1, 16, 8, 16),
+    # one row tile of the right-hand side, six column tiles per wave, the last block ragged
+    (1500, 9, 10, 50, 10), (700, 1, 16, 3, 37),
 ]
 
 
