@@ -1209,7 +1209,7 @@ static RhsDims rhs_dims(int64_t S, int C, int rl, int p, int rr) {
   d.ntl = (p * rr + 15) / 16;
   // a wave owns 2 x 3 output tiles; with a single row tile (left bond <= 16) 1 x 3 while that keeps the four waves
   // to one pass, else 1 x 6, so that no empty tile is multiplied
-  d.nv = d.mt == 1 && d.ntl > 12 ? 6 : 3;
+  d.nv = d.mt > 1 || d.ntl <= 12 ? 3 : (d.ntl <= 24 ? 6 : 12);
   d.bn = (d.ntl + d.nv - 1) / d.nv;
   d.nblocks = ((d.mt + 1) / 2) * d.bn;
   d.passes = (d.nblocks + 3) / 4;
@@ -4548,6 +4548,8 @@ static int rhs_run(const double* L, const double* X, const double* R, const doub
   const size_t lds = (size_t)d.CH * d.W * sizeof(double);
   if (d.mt == 1 && d.nv == 3)
     hipLaunchKernelGGL((rhs_kernel<1, 3>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
+  else if (d.mt == 1 && d.nv == 12)
+    hipLaunchKernelGGL((rhs_kernel<1, 12>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   else if (d.mt == 1)
     hipLaunchKernelGGL((rhs_kernel<1, 6>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   else

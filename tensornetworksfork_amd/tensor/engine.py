@@ -133,10 +133,14 @@ def _rhs_features_first(rl, p, rr):
     every slab of samples once per 4 x 96 output columns ("passes"); the features-first one stages a chunk once
     for all its columns but pays a fixed cost (the GL product, the slab sum) that small sites do not earn back.
     Measured (S = 50 000 .. 54 000, C = 9 .. 10; features-first vs three-factor, us): 48 x 65 x 48 (33 passes)
-    407 / 1558, 24 x 50 x 24 (7) 149 / 249, 1 x 65 x 48 (17) 143 / 694, 1 x 50 x 24 (7) 128 / 213,
-    16 x 40 x 16 (4) 109 / 117, 32 x 16 x 32 (3) 105 / 98, 12 x 30 x 12 (2) 50 / 41, 48 x 65 x 1 (1) 180 / 90."""
+    407 / 1558, 24 x 50 x 24 (7) 149 / 249, 32 x 16 x 32 (3) 105 / 98, 48 x 65 x 1 (1) 180 / 90."""
     if not TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P or rr > 128 or p + rr > 280:
         return False
+    if rl <= 16:
+        # one row tile: a wave of the three-factor kernel owns up to 12 column tiles (48 per pass); measured
+        # (features-first / three-factor, us): 10 x 50 x 10 133 / 73, 16 x 65 x 16 152 / 160, 1 x 50 x 24 124 / 108,
+        # 1 x 65 x 48 139 / 306
+        return (p * rr + 15) // 16 > 96
     blocks = (((rl + 15) // 16 + 1) // 2) * (((p * rr + 15) // 16 + 2) // 3)
     passes = (blocks + 3) // 4
     return passes >= 6
@@ -255,12 +259,19 @@ class LocalProblem:
             return lambda v: ops.rows_matvec(J, H, v.reshape(self.D).contiguous()).reshape(self.shape)
         if self.terms is not None and len(self.terms) == 1 and H.shape[1] == self.C:
             L, X, R = self.terms[0]
-            if _rhs_features_first(L.shape[2], X.shape[1], R.shape[1]) and L.shape[2] <= 128 and L.shape[1] <= 32 and L.shape[1] * L.shape[2] <= 4096:
+            first = _rhs_features_first(L.shape[2], X.shape[1], R.shape[1])
+            if (first or ops.rhs_supported(L.shape[0], 1, L.shape[2], X.shape[1], R.shape[1])) and \
+                    L.shape[2] <= 128 and L.shape[1] <= 32 and L.shape[1] * L.shape[2] <= 4096:
                 # one term with many features: features first (J v), then prediction + Hessian + g.L in one kernel,
-                # then the features-first right-hand side
+                # then the right-hand side of the one "output" GL on the route its shape takes
+                one = _ones_col(L.shape[0], L.device)
+
                 def mv1(v):
                     z = ops.env_step_right(R, X, v.reshape(self.shape).contiguous(), mm32=self.mm32)      # (S, rl)
-                    return ops.rhs_feature(L, X, R, None, mm32=self.mm32, GL=ops.lhl(L, H, z))
+                    GL = ops.lhl(L, H, z)
+                    if first:
+                        return ops.rhs_feature(L, X, R, None, mm32=self.mm32, GL=GL)
+                    return ops.rhs(GL.unsqueeze(1), X, R, one)
                 return mv1
 
         def mv(v):
