@@ -278,9 +278,11 @@ int ttk_lhl_f64(const double* L, const double* H, const double* z, double* GL, i
  * ttk_gemm_rows_f64: T (M,N) (+)= A (M,K) B, rows = samples.  bmode 0: B (K,N) row-major; 1: B(k,(l,r)) =
  * core[l,k,r] with core (rl,K,rr), N = rl*rr: T[s,(l,r)] = sum_p X[s,p] core[l,p,r], the feature
  * contraction done first at a site with many features; 2: B(k,col) = Bt[col,k], Bt (N,K) row-major.
+ * K <= 192 (the 64 x K tile of A stays in LDS; 256 for the float32 form), longer K: TTK_EINVAL.
  *
- * ttk_env_right_dense_f64: ttk_env_step_right_f64 for sites with many features (any p, rr <= 64): the
- * same result by contracting the features first (C p / (C + p) times fewer operations), T never stored.
+ * ttk_env_right_dense_f64: ttk_env_step_right_f64 for sites with many features (p within the same limit,
+ * rr <= 64): the same result by contracting the features first (C p / (C + p) times fewer operations), T
+ * never stored.
  *
  * ttk_lcontract_f64: out[s,c,j] (+)= sum_l L[s,c,l] T[s,l,j], T (S,rl,n): second stage of the left
  * environment step of such a site, and M = L . (A . R) of a feature node's Jacobian.

@@ -262,7 +262,11 @@ template <typename TC>
 static size_t gemm_rows_lds(int K, int kch, int bw) {
   return ((size_t)((K + 3) & ~3) * gemm_rows_astride<TC>() + (size_t)kch * gemm_rows_bstride<TC>(bw)) * sizeof(TC);
 }
-#define GEMM_ROWS_MAX_K 256   // 64 x K A tile + one B chunk stay below 160 KiB
+// longest K: the 64 x K A tile + one 64 x 96 B chunk stay below 158 KiB
+template <typename TC>
+static constexpr int gemm_rows_max_k() {
+  return sizeof(TC) == 8 ? 192 : 256;
+}
 
 // ---------------------------------------------------------------------------------------
 // Right-environment step of a site with many features, core block resident:
@@ -928,7 +932,7 @@ static int gemm_rows_launch(const double* A, const double* B, double* T, int64_t
   const dim3 grid((unsigned)((M + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
   const int kch = gemm_rows_chunk(K);
-  if (K > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  if (K > gemm_rows_max_k<TC>()) return TTK_EINVAL;
   const size_t lds = gemm_rows_lds<TC>(K, kch, 64);
   if (!gemm_rows_allow_lds<TC>()) return TTK_ELAUNCH;
   const double* none = nullptr;
@@ -947,7 +951,7 @@ static int gemm_rows_launch(const double* A, const double* B, double* T, int64_t
 template <typename TC>
 static int env_right_dense_launch(const double* R, const double* X, const double* core, double* out, int64_t S, int rl, int p,
                                   int rr, int accumulate, void* stream) {
-  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > GEMM_ROWS_MAX_K) return TTK_EINVAL;
+  if (!R || !X || !core || !out || S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > gemm_rows_max_k<TC>()) return TTK_EINVAL;
   if (!gemm_rows_allow_lds<TC>()) return TTK_ELAUNCH;
   const dim3 grid((unsigned)((S + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
@@ -1097,7 +1101,7 @@ int ttk_gemm_rows_mm32(const double* A, const double* B, double* T, int64_t M, i
 }
 
 int ttk_env_right_dense_ok(int64_t S, int rl, int p, int rr, int mm32) {
-  if (S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > GEMM_ROWS_MAX_K) return 0;
+  if (S < 1 || rl < 1 || p < 1 || rr < 1 || rr > 128 || p > (mm32 ? gemm_rows_max_k<float>() : gemm_rows_max_k<double>())) return 0;
   if (rr <= 64) return 1;
   const int tpl = (rr + 15) / 16;
   return (mm32 ? env_resident_dims<float>(S, rl, p, 1, tpl).lds : env_resident_dims<double>(S, rl, p, 1, tpl).lds) ? 1 : 0;

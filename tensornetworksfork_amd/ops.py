@@ -43,12 +43,24 @@ def env_step_left(E, X, core, out=None):
         return out
     rc = _lib.lib().ttk_env_step_left_f64(_chk(E, "E"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
                                           _chk(out, "out", (S, C, rr)), S, C, rl, p, rr, int(acc), _stream(E))
+    if rc == -1 and p > FEATURE_BLOCK:      # rows of rl + p doubles beyond the LDS image: sum over feature blocks
+        for k, (a, b) in enumerate(_feature_blocks(p)):
+            Xb, cb = X[:, a:b].contiguous(), core[:, a:b, :].contiguous()
+            rc = _lib.lib().ttk_env_step_left_f64(E.data_ptr(), Xb.data_ptr(), cb.data_ptr(), out.data_ptr(), S, C, rl, b - a, rr,
+                                                  int(acc or k > 0), _stream(E))
+            _lib.check(rc, "ttk_env_step_left_f64")
+        return out
     _lib.check(rc, "ttk_env_step_left_f64")
     return out
 
 
 DENSE_MIN_P = 16    # from this many features on a site contracts its features first (ttk_dense kernels)
-DENSE_MAX_P = 256   # ... up to what the row GEMM keeps in LDS (beyond: the streaming Khatri-Rao kernels)
+DENSE_MAX_P = 192   # ... up to what the row GEMM keeps in LDS (beyond: the streaming Khatri-Rao kernels)
+FEATURE_BLOCK = 128  # a site whose sample rows are too wide for any kernel's LDS image goes feature block by feature block
+
+
+def _feature_blocks(p):
+    return [(a, min(a + FEATURE_BLOCK, p)) for a in range(0, p, FEATURE_BLOCK)]
 
 
 def env_step_right(R, X, core, out=None, mm32=False):
@@ -73,6 +85,13 @@ def env_step_right(R, X, core, out=None, mm32=False):
         return out
     rc = _lib.lib().ttk_env_step_right_f64(_chk(R, "R"), _chk(X, "X", (S, p)), _chk(core, "core", (rl, p, rr)),
                                            _chk(out, "out", (S, rl)), S, rl, p, rr, int(acc), _stream(R))
+    if rc == -1 and p > FEATURE_BLOCK:      # rows of rr + p doubles beyond the LDS image: sum over feature blocks
+        for k, (a, b) in enumerate(_feature_blocks(p)):
+            Xb, cb = X[:, a:b].contiguous(), core[:, a:b, :].contiguous()
+            rc = _lib.lib().ttk_env_step_right_f64(R.data_ptr(), Xb.data_ptr(), cb.data_ptr(), out.data_ptr(), S, rl, b - a, rr,
+                                                   int(acc or k > 0), _stream(R))
+            _lib.check(rc, "ttk_env_step_right_f64")
+        return out
     _lib.check(rc, "ttk_env_step_right_f64")
     return out
 
@@ -254,6 +273,9 @@ def jvp(L, X, R, H, v):
     hu = torch.empty((S, C), dtype=F64, device=L.device)
     rc = _lib.lib().ttk_jvp_f64(_chk(L, "L"), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), _chk(H, "H", (S, C, C)),
                                 _chk(v, "v", (rl, p, rr)), tmp.data_ptr(), hu.data_ptr(), S, C, rl, p, rr, _stream(L))
+    if rc == -1 and p > FEATURE_BLOCK:      # too wide for the one call: the same three steps, the first in feature blocks
+        u = predict(env_step_left(L, X, v), R)
+        return hess_left(H, u.unsqueeze(-1)).squeeze(-1)
     _lib.check(rc, "ttk_jvp_f64")
     return hu
 

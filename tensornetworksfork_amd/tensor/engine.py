@@ -107,7 +107,7 @@ def pair_classes_many(Xs):
 
 DENSE_ROWS_KERNEL_MAX_D = 128   # explicit Jacobian rows up to this width go through the Khatri-Rao kernels
 TWO_STAGE_MIN_P = 16    # from this many features on, J v and the environment steps contract the features first
-TWO_STAGE_MAX_P = 256   # ... up to what the row GEMM keeps in LDS; beyond, the streaming Khatri-Rao kernels
+TWO_STAGE_MAX_P = 192   # ... up to what the row GEMM keeps in LDS; beyond, the streaming Khatri-Rao kernels
 
 
 _ONES = {}
@@ -251,7 +251,8 @@ class LocalProblem:
         """v -> (J^T H J) v, canonical shape, never forming the Gram matrix."""
         if self.terms is not None and len(self.terms) == 1 and not TWO_STAGE_MIN_P <= self.terms[0][1].shape[1] <= TWO_STAGE_MAX_P:
             L, X, R = self.terms[0]
-            return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
+            if ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
+                return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
         if self.J is not None and H.shape[1] == self.C and ops.rows_matvec_supported(self.S, self.C, self.D):
             # explicit rows of a narrow node (conv filter): the whole operator in one pass over the rows

@@ -56,6 +56,34 @@ def test_env_steps(S, C, rl, p, rr):
 
 
 @gpu
+@pytest.mark.parametrize("S,C,rl,p,rr", [(64, 1, 33, 400, 2), (300, 2, 64, 257, 1), (129, 1, 24, 257, 64), (65, 9, 24, 256, 31),
+                                         (200, 3, 16, 193, 63), (64, 1, 1, 256, 1), (257, 1, 128, 256, 1), (70, 1, 96, 400, 7)])
+def test_sites_with_hundreds_of_features(S, C, rl, p, rr):
+    """More features than the features-first kernels keep in LDS (192), with bonds that make a sample row too wide
+    for the streaming kernels' LDS image as well: the steps go feature block by feature block, the right-hand side
+    features last; the local problem of such a site against the oracle on every route the sweep takes."""
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor import engine
+    dev = _dev()
+    L, X, core, R = _rand((S, C, rl), 1), _rand((S, p), 2), _rand((rl, p, rr), 3), _rand((S, rr), 4)
+    g = _rand((S, C), 5)
+    Hh = _rand((S, C, C), 6)
+    H = (Hh @ Hh.transpose(1, 2) + 0.1 * torch.eye(C, dtype=torch.float64)).contiguous()
+    Ld, Xd, cd, Rd = L.to(dev), X.to(dev), core.to(dev), R.to(dev)
+    assert G.rel_err(ops.env_step_left(Ld, Xd, cd), O.env_left_step(L, core, X)) < TOL
+    assert G.rel_err(ops.env_step_right(Rd, Xd, cd), O.env_right_step(R, core, X)) < TOL
+    base_l, base_r = _rand((S, C, rr), 7), _rand((S, rl), 8)
+    assert G.rel_err(ops.env_step_left(Ld, Xd, cd, out=base_l.to(dev)), base_l + O.env_left_step(L, core, X)) < TOL
+    assert G.rel_err(ops.env_step_right(Rd, Xd, cd, out=base_r.to(dev)), base_r + O.env_right_step(R, core, X)) < TOL
+    lp = engine.LocalProblem(S, C, (rl, p, rr), cd, lambda t: t, terms=[(Ld, Xd, Rd)])
+    assert G.rel_err(lp.rhs(g.to(dev)), O.local_rhs(L, X, R, g)) < TOL
+    u = torch.einsum('scr,sr->sc', O.env_left_step(L, core, X), R)
+    assert G.rel_err(lp.jv(cd), u) < TOL
+    assert G.rel_err(lp.matvec_fn(H.to(dev))(cd), O.local_matvec(L, X, R, H, core)) < TOL
+    assert G.rel_err(ops.jvp(Ld, Xd, Rd, H.to(dev), cd), torch.einsum('scd,sd->sc', H, u)) < TOL
+
+
+@gpu
 @pytest.mark.parametrize("kind,C", [("square", 1), ("square", 3), ("mse", 1), ("mse", 4), ("xe", 1), ("xe", 2), ("xe", 9)])
 def test_losses(kind, C):
     from tensornetworksfork_amd import ops
