@@ -120,6 +120,30 @@ for case in range(NCASES):
         if D <= 3000 and ops.gram_supported(S, C, rl, p, rr, True):
             Aref = torch.einsum('scx,scd,sdy->xy', Jref, H, Jref)
             check("gram", shape, lambda: ops.gram_expand(ops.gram(L, H, X, R, sym=True)), lambda: Aref)
+            # unsymmetric per-sample matrix in place of the Hessian (the other compressed layout)
+            check("gram unsym", shape, lambda: ops.gram_expand(ops.gram(L, Hs.contiguous(), X, R, sym=False)),
+                  lambda: torch.einsum('scx,scd,sdy->xy', Jref, Hs, Jref))
+            # powers of one variable as features: pairs (p,q) with equal p+q share one slice of the Gram
+            from tensornetworksfork_amd.tensor.engine import pair_classes
+            xv = r(S) * 2
+            Xp = torch.stack([xv ** k for k in range(p)], dim=-1).contiguous()
+            rep = pair_classes(Xp)
+            Jp = torch.einsum('scl,sp,sr->sclpr', L, Xp, R).reshape(S, C, D)
+            Ap = torch.einsum('scx,scd,sdy->xy', Jp, H, Jp)
+            check("gram classes", shape, lambda: ops.gram_expand(ops.gram(L, H, Xp, R, sym=True, pair_rep=rep)), lambda: Ap, tol=1e-10)
+            # ridge Cholesky solve straight from the compressed Gram
+            wsg = ops.gram(L, H, X, R, sym=True)
+            bb, ww = r(rl, p, rr), r(rl, p, rr)
+            sc = ops.gram_scale(wsg)
+            ridge = 0.3
+
+            def solved():
+                xsol, info = ops.chol_solve_gram(wsg, bb, ww, sc, ridge)
+                assert int(info.item()) == 0
+                return xsol
+            check("chol_solve_gram", shape, solved,
+                  lambda: torch.linalg.solve(Aref / sc + ridge * torch.eye(D, dtype=torch.float64, device=dev),
+                                             -(bb.reshape(-1) / sc + ridge * ww.reshape(-1))), tol=1e-9)
         if D <= 512:
             vv = v.reshape(D)
             check("rows_dot", shape, lambda: ops.rows_dot(Jref, vv), lambda: torch.einsum('scx,x->sc', Jref, vv))
@@ -127,6 +151,21 @@ for case in range(NCASES):
                 check("rows_matvec", shape, lambda: ops.rows_matvec(Jref, H, vv),
                       lambda: torch.einsum('scx,scd,sd->x', Jref, H, torch.einsum('sdx,x->sd', Jref, vv)))
                 check("rows_rhs", shape, lambda: ops.rows_rhs(Jref, gr), lambda: torch.einsum('scx,sc->x', Jref, gr))
+    m, n = rl * p, rr
+    if m * n <= 200000:
+        Aq = r(m, n)
+        say("   qr", (m, n))
+        try:
+            Q, Rq = ops.qr(Aq)
+            Qr, Rr = torch.linalg.qr(Aq, mode='reduced')
+            for name, got, want in (("qr Q", Q, Qr), ("qr R", Rq, Rr)):
+                e = rel(got, want)
+                if not e < 1e-10:
+                    bad.append((name, (m, n), e))
+                    print("MISMATCH", name, (m, n), e, flush=True)
+        except (_lib.TTKError, ValueError) as e:
+            unsupported.setdefault("qr", []).append((m, n))
+            say("     unsupported:", e)
     if case % 20 == 0:
         print("case", case, shape, "mismatches so far", len(bad), flush=True)
 
