@@ -536,7 +536,11 @@ class TensorNetwork:
                            max_norm=None, eps_per_node=False, **legacy):
         """DMRG sweeps with a Gauss-Newton solve per core (tensor/network.py:379-608).
         Same schedule, ridge schedule, skip rule, callbacks and return value as the
-        reference; the mini-batch loop is replaced by one pass over the resident data."""
+        reference; the mini-batch loop is replaced by one pass over the resident data.
+        `update_or_reset_stack` is accepted and has no effect: the cached environments are always the ones of
+        the current nodes.  (The reference's 'update' mode, which none of its callers selects, refreshes one
+        environment per update and leaves the prediction, which is contracted at the first node, on stale ones:
+        tensor/network.py:115-131 with 489-492.)"""
         for k_ in legacy:
             if k_ not in _LEGACY_KWARGS:
                 raise TypeError(f"accumulating_swipe() got an unexpected keyword argument '{k_}'")
