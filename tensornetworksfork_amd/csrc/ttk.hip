@@ -886,8 +886,10 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
                                                          double* __restrict__ F) {
   const int CW = C * rl, NX = p * (p + 1) / 2, W = 2 * CW + NX + rr + 1;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= ((S + 3) & ~(int64_t)3) * W) return;
-  const int64_t s_ = idx / W;
+  const int64_t total = ((S + 3) & ~(int64_t)3) * W;
+  if (idx >= total) return;
+  // (a 32-bit division where the table has fewer than 2^31 entries: the 64-bit one is several times the work)
+  const int64_t s_ = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)idx / (unsigned)W) : idx / W;
   const int j = (int)(idx - s_ * W);
   double v = 0.0;
   if (s_ >= S) {
@@ -1784,6 +1786,28 @@ __global__ __launch_bounds__(256) void solve_rhs_kernel(const double* __restrict
   double v = scale ? b[idx] / scale[0] : b[idx];
   if (w) v += ridge * w[idx];
   out[idx] = -v;
+}
+
+// Everything the single-launch solve needs before its factorisation, in one launch instead of two kernels and
+// three fills: the right-hand-side block row of the storage (row 0 = -(b/scale + ridge w), zero behind it and in
+// the 63 rows below), the control words at zero with the spin limit in word 4, the pivot report at zero.
+__global__ __launch_bounds__(256) void solve_prep_kernel(const double* __restrict__ b, const double* __restrict__ w,
+                                                          const double* __restrict__ scale, double ridge,
+                                                          double* __restrict__ rows, int64_t nrows_elems, int64_t D,
+                                                          unsigned* __restrict__ ctl, int nctl, unsigned spin,
+                                                          int* __restrict__ info) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < nrows_elems) {
+    double v = 0.0;
+    if (idx < D) {
+      v = scale ? b[idx] / scale[0] : b[idx];
+      if (w) v += ridge * w[idx];
+      v = -v;
+    }
+    rows[idx] = v;
+  }
+  if (idx < nctl) ctl[idx] = idx == 4 ? spin : 0u;
+  if (idx == 0) *info = 0;
 }
 
 __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y,
@@ -4431,21 +4455,31 @@ static int chol_back_substitute(hipStream_t st, double* aug, int ld, int nb, con
 
 // gs != nullptr: the matrix is still in the compressed Gram workspace gs->G (see DagGram); the single-launch
 // factorisation reads it from there, the multi-launch one has it expanded into the storage first.
-static int chol_solve_impl(void* chol_ws, int n, double* x, int* info, hipStream_t st, const DagGram* gs) {
+// whether a solve of nb block rows runs the single-launch factorisation
+static bool chol_uses_dag(int nb) {
+  const int64_t aug_bytes = (int64_t)(nb + 1) * CHB * nb * CHB * (int64_t)sizeof(double);
+  return (g_chol_mode == 1 || (g_chol_mode < 0 && nb >= CHOL_DAG_MIN_NB)) && aug_bytes < (int64_t(1) << 32);
+}
+
+// prepped: solve_prep_kernel has already cleared the pivot report and the control words (single-launch form only)
+static int chol_solve_impl(void* chol_ws, int n, double* x, int* info, hipStream_t st, const DagGram* gs,
+                           bool prepped = false) {
   const int nb = (n + CHB - 1) / CHB;
   const int ld = nb * CHB;
   const int nbr = nb + 1;
   const int nrows = nbr * CHB, ncols = ld;
   double* aug = (double*)chol_ws;
   double* invL = aug + (int64_t)nbr * CHB * ld;
-  if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return TTK_ELAUNCH;
   const int64_t aug_bytes = (int64_t)nbr * CHB * ld * (int64_t)sizeof(double);
-  const bool dag = (g_chol_mode == 1 || (g_chol_mode < 0 && nb >= CHOL_DAG_MIN_NB)) && aug_bytes < (int64_t(1) << 32);
+  const bool dag = chol_uses_dag(nb);
+  if (!(prepped && dag) && hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return TTK_ELAUNCH;
   if (dag) {
     // every word the kernel polls or counts starts at zero
     unsigned* ctl = (unsigned*)((char*)chol_ws + chol_ctl_offset(nb));
-    if (hipMemsetAsync(ctl, 0, (size_t)chol_ctl_bytes(nb), st) != hipSuccess) return TTK_ELAUNCH;
-    if (hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), g_dag_spin_limit, 1, st) != hipSuccess) return TTK_ELAUNCH;
+    if (!prepped) {
+      if (hipMemsetAsync(ctl, 0, (size_t)chol_ctl_bytes(nb), st) != hipSuccess) return TTK_ELAUNCH;
+      if (hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), g_dag_spin_limit, 1, st) != hipSuccess) return TTK_ELAUNCH;
+    }
     // every slot of the device gets a workgroup, so that each compute unit sees its first arrival at once
     const int slots = chol_dag_slots();
     int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
@@ -4510,9 +4544,18 @@ int ttk_chol_solve_gram_f64(const void* gram_ws, int rl, int p, int rr, int sym_
   const int ld = nb * CHB;
   double* aug = (double*)chol_ws;
   // the right-hand side row (and the zero rows below it) is all that goes into the storage up front
-  if (hipMemsetAsync(aug + (int64_t)ld * ld, 0, (size_t)CHB * ld * sizeof(double), st) != hipSuccess) return TTK_ELAUNCH;
-  hipLaunchKernelGGL(solve_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, w, scale, ridge,
-                     aug + (int64_t)ld * ld, (int64_t)n);
+  const bool prepped = chol_uses_dag(nb);
+  if (prepped) {
+    unsigned* ctl = (unsigned*)((char*)chol_ws + chol_ctl_offset(nb));
+    const int64_t elems = (int64_t)CHB * ld;
+    hipLaunchKernelGGL(solve_prep_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, b, w, scale, ridge,
+                       aug + (int64_t)ld * ld, elems, (int64_t)n, ctl, (int)(chol_ctl_bytes(nb) / (int64_t)sizeof(unsigned)),
+                       g_dag_spin_limit, info);
+  } else {
+    if (hipMemsetAsync(aug + (int64_t)ld * ld, 0, (size_t)CHB * ld * sizeof(double), st) != hipSuccess) return TTK_ELAUNCH;
+    hipLaunchKernelGGL(solve_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, w, scale, ridge,
+                       aug + (int64_t)ld * ld, (int64_t)n);
+  }
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   DagGram gs;
@@ -4522,7 +4565,7 @@ int ttk_chol_solve_gram_f64(const void* gram_ws, int rl, int p, int rr, int sym_
   gs.rl = rl; gs.p = p; gs.rr = rr; gs.sym = sym_left; gs.NX = d.NX; gs.NRpad = d.NRpad; gs.D = n;
   gs.inv_rr = 1.0f / (float)rr;
   gs.inv_p = 1.0f / (float)p;
-  return chol_solve_impl(chol_ws, n, x, info, st, &gs);
+  return chol_solve_impl(chol_ws, n, x, info, st, &gs, prepped);
 }
 
 int64_t ttk_rhs_ws_bytes(int64_t S, int C, int rl, int p, int rr) {
