@@ -1354,15 +1354,27 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
 #pragma unroll 2
         for (int ks = 0; ks < steps; ++ks) {
           const double* row = smem + (ks * 4 + kq) * W;
-          double av[MU], bv[NV];
+          double av[MU];
 #pragma unroll
           for (int u = 0; u < MU; ++u) av[u] = row[oA[u]];
+          // six column tiles at a time: one batch of LDS reads, then their products and MFMAs (all of a wide
+          // tile row at once leaves the compiler no registers to batch the reads in)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) bv[v] = row[oX[v]] * row[oR[v]];
+          for (int h = 0; h < NV; h += 6) {
+            constexpr int HV = NV < 6 ? NV : 6;
+            double xv[HV], rv[HV];
 #pragma unroll
-          for (int u = 0; u < MU; ++u)
+            for (int v = 0; v < HV; ++v) {
+              xv[v] = row[oX[h + v]];
+              rv[v] = row[oR[h + v]];
+            }
 #pragma unroll
-            for (int v = 0; v < NV; ++v) acc[u][v] = MFMA_F64(av[u], bv[v], acc[u][v]);
+            for (int v = 0; v < HV; ++v) {
+              const double bv = xv[v] * rv[v];
+#pragma unroll
+              for (int u = 0; u < MU; ++u) acc[u][h + v] = MFMA_F64(av[u], bv, acc[u][h + v]);
+            }
+          }
         }
       }
     }
