@@ -1,13 +1,20 @@
-import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Time ops.qr at given shapes: python tools/time_qr.py m n [m n ...]"""
+import sys
 import torch
+sys.path.insert(0, ".")
 from tensornetworksfork_amd import ops
+
+a = [int(v) for v in sys.argv[1:]]
 dev = torch.device("cuda:0")
-for (m, n) in [(192, 32), (36, 6), (36, 32), (192, 6), (5, 9), (256, 32), (1, 1), (1200, 24), (50, 65)]:
-    A = torch.randn(m, n, dtype=torch.float64, device=dev)
-    Q, R = ops.qr(A)
-    Qr, Rr = torch.linalg.qr(A.cpu())
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): Q, R = ops.qr(A)
+for k in range(0, len(a), 2):
+    m, n = a[k:k + 2]
+    A = torch.rand(m, n, dtype=torch.float64, device=dev)
+    for _ in range(5):
+        ops.qr(A)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.qr(A)
+    e1.record()
     torch.cuda.synchronize()
-    print((m, n), "us", (time.perf_counter() - t0) / 20 * 1e6, "errQ", (Q.cpu() - Qr).abs().max().item(), "errR", (R.cpu() - Rr).abs().max().item())
+    print((m, n), "%.1f us" % (e0.elapsed_time(e1) * 20))
