@@ -1209,9 +1209,22 @@ static RhsDims rhs_dims(int64_t S, int C, int rl, int p, int rr) {
   RhsDims d;
   d.mt = (rl + 15) / 16;
   d.ntl = (p * rr + 15) / 16;
-  // a wave owns 2 x 3 output tiles; with a single row tile (left bond <= 16) 1 x 3 while that keeps the four waves
-  // to one pass, else 1 x 6, so that no empty tile is multiplied
-  d.nv = d.mt > 1 || d.ntl <= 12 ? 3 : (d.ntl <= 24 ? 6 : 12);
+  // a wave owns 2 x 3 output tiles; with a single row tile (left bond <= 16) 1 x 3, 1 x 6, 1 x 8 or 1 x 12: the
+  // narrowest that keeps the four waves to one pass, so that no empty tile is multiplied
+  d.nv = 3;
+  if (d.mt == 1) {
+    // passes x (tiles a wave multiplies per pass + what staging a pass costs, in the same unit)
+    const int cand[4] = {3, 6, 8, 12};
+    int best = 1 << 30;
+    for (int k = 0; k < 4; ++k) {
+      const int bn = (d.ntl + cand[k] - 1) / cand[k];
+      const int cost = ((bn + 3) / 4) * (cand[k] + 4);
+      if (cost < best) {
+        best = cost;
+        d.nv = cand[k];
+      }
+    }
+  }
   d.bn = (d.ntl + d.nv - 1) / d.nv;
   d.nblocks = ((d.mt + 1) / 2) * d.bn;
   d.passes = (d.nblocks + 3) / 4;
@@ -1357,11 +1370,11 @@ __global__ __launch_bounds__(256, 2) void rhs_kernel(const double* __restrict__ 
           double av[MU];
 #pragma unroll
           for (int u = 0; u < MU; ++u) av[u] = row[oA[u]];
-          // six column tiles at a time: one batch of LDS reads, then their products and MFMAs (all of a wide
+          // up to six column tiles at a time: one batch of LDS reads, then their products and MFMAs (all of a wide
           // tile row at once leaves the compiler no registers to batch the reads in)
+          constexpr int HV = NV <= 6 ? NV : (NV % 6 == 0 ? 6 : 4);
 #pragma unroll
-          for (int h = 0; h < NV; h += 6) {
-            constexpr int HV = NV < 6 ? NV : 6;
+          for (int h = 0; h < NV; h += HV) {
             double xv[HV], rv[HV];
 #pragma unroll
             for (int v = 0; v < HV; ++v) {
@@ -4603,6 +4616,8 @@ static int rhs_run(const double* L, const double* X, const double* R, const doub
   const size_t lds = (size_t)d.CH * d.W * sizeof(double);
   if (d.mt == 1 && d.nv == 3)
     hipLaunchKernelGGL((rhs_kernel<1, 3>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
+  else if (d.mt == 1 && d.nv == 8)
+    hipLaunchKernelGGL((rhs_kernel<1, 8>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   else if (d.mt == 1 && d.nv == 12)
     hipLaunchKernelGGL((rhs_kernel<1, 12>), dim3((unsigned)d.nslabs), dim3(256), lds, st, A, X, R, gx, S, rl, p, rr, d, ws);
   else if (d.mt == 1)
