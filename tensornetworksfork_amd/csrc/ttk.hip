@@ -1124,18 +1124,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const double* __
 // partial == out this only replicates, in place).
 __global__ __launch_bounds__(256) void gram_reduce_classed_kernel(const double* __restrict__ partial, int nslabs,
                                                                    int64_t stride, GramDims gd, double* __restrict__ out) {
+  // two adjacent columns per thread (rows are a multiple of 48 columns long and 16-byte aligned): 16-byte
+  // loads, four slabs in flight per pass of the loop; the slabs are added in their order for either column
+  const int half = gd.NRpad >> 1;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)gd.MPpad * gd.nrep * gd.NRpad) return;
-  const int c = (int)(idx % gd.NRpad);
-  const int64_t ak = idx / gd.NRpad;
+  if (idx >= (int64_t)gd.MPpad * gd.nrep * half) return;
+  const int c = 2 * (int)(idx % half);
+  const int64_t ak = idx / half;
   const int k = (int)(ak % gd.nrep);
   const int64_t a = ak / gd.nrep;
   const int b0 = gd.reps[k];
   const int64_t src = (a * gd.NX + b0) * gd.NRpad + c;
-  double acc = 0.0;
-  for (int s_ = 0; s_ < nslabs; ++s_) acc += partial[(int64_t)s_ * stride + src];
+  double acc0 = 0.0, acc1 = 0.0;
+  int s_ = 0;
+  for (; s_ + 4 <= nslabs; s_ += 4) {
+    double2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *(const double2*)(partial + (int64_t)(s_ + q) * stride + src);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc0 += v[q].x;
+      acc1 += v[q].y;
+    }
+  }
+  for (; s_ < nslabs; ++s_) {
+    const double2 v = *(const double2*)(partial + (int64_t)s_ * stride + src);
+    acc0 += v.x;
+    acc1 += v.y;
+  }
   for (int b = b0; b < gd.NX; ++b)   // members come after their representative
-    if (gd.repof[b] == b0) out[(a * gd.NX + b) * gd.NRpad + c] = acc;
+    if (gd.repof[b] == b0) *(double2*)(out + (a * gd.NX + b) * gd.NRpad + c) = double2{acc0, acc1};
 }
 
 __global__ __launch_bounds__(1024) void gram_scale_kernel(const double* __restrict__ G, int rl, int p, int rr, int sym,
@@ -4325,7 +4343,7 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;
   if (d.classed) {
-    const int64_t nred = (int64_t)d.MPpad * d.nrep * d.NRpad;
+    const int64_t nred = (int64_t)d.MPpad * d.nrep * (d.NRpad / 2);
     hipLaunchKernelGGL(gram_reduce_classed_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st,
                        (const double*)partial, d.nslabs, d.gsize, d, G);
     rc = ttk_launch_status();
