@@ -21,7 +21,8 @@ def test_rhs_static_matches_rhs_twice():
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     assert lib.ttk_rhs_static_max_bytes() == 32 * 1024 * 1024
-    for (S, C, rl, p, rr), seed in (((54000, 1, 32, 6, 32), 1), ((3001, 3, 16, 5, 24), 2), ((130, 2, 6, 4, 6), 3)):
+    for (S, C, rl, p, rr), seed in (((54000, 1, 32, 6, 32), 1), ((3001, 3, 16, 5, 24), 2), ((5000, 9, 10, 50, 10), 5),
+                                   ((4000, 1, 16, 40, 16), 6), ((130, 2, 6, 4, 6), 3)):
         L, X, R, g = _case(S, C, rl, p, rr, seed, dev)
         nbytes = lib.ttk_rhs_ws_bytes(S, C, rl, p, rr)
         assert 0 < nbytes <= lib.ttk_rhs_static_max_bytes()
