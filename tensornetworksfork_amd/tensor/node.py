@@ -261,7 +261,8 @@ class TensorNode:
             step_norm, weight_norm = torch.norm(step), torch.norm(self.tensor)
             if step_norm > weight_norm:
                 step = step * (weight_norm / step_norm)
-        updated = self.tensor + lr * step
+        unit = isinstance(lr, (int, float)) and lr == 1.0                              # 1.0 * step is step: one kernel less
+        updated = self.tensor + step if unit else self.tensor + lr * step
         if max_norm is not None:
             n = torch.norm(updated)
             if n > max_norm:
