@@ -137,6 +137,39 @@ def test_ttreg_fit_golden(name):
     assert G.rel_err(est.predict(d["X"][:50]), d["pred"]) < 1e-5
 
 
+def _random_estimator_cases():
+    import os
+    path = os.path.join(G.GOLDEN, "estimators_random.npz")
+    return list(range(int(np.load(path)["ncases"]))) if os.path.exists(path) else []
+
+
+@gpu
+@pytest.mark.parametrize("case", _random_estimator_cases())
+def test_random_estimator_golden(case):
+    """Randomly drawn estimator configurations (every model_type, cum-sum, linear maps, trained operators, early
+    stopping, both tasks, both feature maps), fitted by the reference in the build container
+    (oracle/gen_golden_estimators.py): validation history and predictions."""
+    import json
+    from tensornetworksfork_amd.models.tensor_train import TensorTrainRegressor
+    from tensornetworksfork_amd.models.tnml import TNMLRegressor
+    from tensornetworksfork_amd.tensor.bregman import XEAutogradBregman
+    torch.set_default_dtype(torch.float64)
+    d = G.load("estimators_random")
+    p = f"c{case}_"
+    meta = json.loads(str(d[p + "meta"]))
+    cls = TensorTrainRegressor if meta["which"] == "tt" else TNMLRegressor
+    extra = dict(task=meta["task"]) if meta["which"] == "tt" else {}
+    bf = XEAutogradBregman(w=1.0) if meta["task"] == "classification" else None
+    torch.manual_seed(int(meta["torch_seed"]))      # layers that take `seed` without using it draw from the global generator
+    est = cls(device=DEV, bf=bf, **extra, **meta["kw"])
+    est.fit(d[p + "X"], d[p + "y"])
+    vh = est._early_stopper.val_history
+    got = np.array([vh[k] for k in sorted(vh)])
+    assert got.shape == d[p + "val_history"].shape, meta
+    assert np.allclose(got, d[p + "val_history"], rtol=1e-5, atol=1e-12), meta
+    assert G.rel_err(est.predict(d[p + "Xt"]), d[p + "pred"]) < 1e-5, meta
+
+
 @gpu
 @pytest.mark.parametrize("name", G.names("lanczos_"))
 def test_lanczos_golden(name):

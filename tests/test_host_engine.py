@@ -47,6 +47,11 @@ def test_estimators_host_logic(name, api):
     (api.test_tnml_fit_golden if name.startswith("tnml_") else api.test_ttreg_fit_golden)(name)
 
 
+@pytest.mark.parametrize("case", range(24))
+def test_random_estimators_host_logic(case, api):
+    api.test_random_estimator_golden(case)
+
+
 @pytest.mark.parametrize("name", G.names("net_"))
 def test_other_topologies_host_logic(name, cpu_kernels):
     from tests import test_nets_gpu as nets
