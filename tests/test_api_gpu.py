@@ -137,6 +137,50 @@ def test_ttreg_fit_golden(name):
     assert G.rel_err(est.predict(d["X"][:50]), d["pred"]) < 1e-5
 
 
+def _random_cases(fname):
+    import os
+    path = os.path.join(G.GOLDEN, fname)
+    return list(range(int(np.load(path)["ncases"]))) if os.path.exists(path) else []
+
+
+@gpu
+@pytest.mark.parametrize("case", _random_cases("swipes_random.npz"))
+def test_random_swipe_golden(case):
+    """Randomly drawn accumulating_swipe calls on tensor-train layers as the reference runs them in the build
+    container (oracle/gen_golden_swipes.py): node_order lists and pairs, eps lists per node, eps_decay, adaptive
+    steps with min / max norm, a convergence_criterion that stops the sweep, one tensor or a list as input.  Return
+    value, the sequence of block callbacks, the losses and the prediction after the sweep."""
+    import json
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction, XEAutogradBregman
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    torch.set_default_dtype(torch.float64)
+    d = G.load("swipes_random")
+    p = f"c{case}_"
+    m = json.loads(str(d[p + "meta"]))
+    layer = TensorTrainLayer(m["N"], m["r"], m["f"], output_shape=m["C"], constrict_bond=True, seed=m["layer_seed"]).to(DEV)
+    tn = layer.tensor_network
+    xs = [G.T(d[p + f"x{i}"], DEV) for i in range(m["N"])]
+    x = xs if m["list_input"] else xs[0]
+    y = G.T(d[p + "y"], DEV)
+    kw = dict(m["kw"])
+    if m["order"] is not None:
+        pick = lambda idx: [tn.train_nodes[i] for i in idx]      # noqa: E731
+        kw["node_order"] = (pick(m["order"][0]), pick(m["order"][1])) if m["order_is_pair"] else pick(m["order"])
+    losses, blocks, calls = [], [], [0]
+
+    def crit():
+        calls[0] += 1
+        return m["stop_after"] is not None and calls[0] >= m["stop_after"]
+    ok = tn.accumulating_swipe(x, y, XEAutogradBregman(w=1.0) if m["loss"] == "xe" else SquareBregFunction(), disable_tqdm=True,
+                               verbose=0, loss_callback=lambda NS, n, l: losses.append(l),
+                               block_callback=lambda NS, n: blocks.append([NS, n.name]), convergence_criterion=crit, **kw)
+    assert bool(ok) == m["ok"] and blocks == m["blocks"], m
+    ref = d[p + "losses"]
+    assert len(losses) == len(ref), m
+    assert np.allclose(np.array(losses), ref, rtol=1e-6, atol=0), m
+    assert G.rel_err(tn.forward(x, to_tensor=True), d[p + "pred"]) < 1e-5, m
+
+
 def _random_estimator_cases():
     import os
     path = os.path.join(G.GOLDEN, "estimators_random.npz")

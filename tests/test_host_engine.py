@@ -48,6 +48,11 @@ def test_estimators_host_logic(name, api):
 
 
 @pytest.mark.parametrize("case", range(24))
+def test_random_swipes_host_logic(case, api):
+    api.test_random_swipe_golden(case)
+
+
+@pytest.mark.parametrize("case", range(24))
 def test_random_estimators_host_logic(case, api):
     api.test_random_estimator_golden(case)
 
