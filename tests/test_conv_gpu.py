@@ -202,3 +202,58 @@ def check_gradient_swipe_cifar_call(device):
 @gpu
 def test_gradient_swipe_cifar_call():
     check_gradient_swipe_cifar_call(DEV)
+
+
+def _random_conv_cases():
+    import os
+    import numpy as np
+    path = os.path.join(G.GOLDEN, "conv_random.npz")
+    return list(range(int(np.load(path)["ncases"]))) if os.path.exists(path) else []
+
+
+def check_random_conv(case, DEV):
+    """One randomly drawn small conv tensor train as the reference runs it in the build container
+    (oracle/gen_golden_conv_random.py): forward, b and A v of every train node, the losses of a ridge_cholesky
+    sweep and of a two-iteration Lanczos sweep and the prediction after each."""
+    import json
+    from tensornetworksfork_amd.tensor.layers import TensorConvolutionTrainLayer
+    torch.set_default_dtype(torch.float64)
+    d = G.load("conv_random")
+    p = f"c{case}_"
+    m = json.loads(str(d[p + "meta"]))
+    x, y = G.T(d[p + "x"], DEV), G.T(d[p + "y"], DEV)
+
+    def fresh():
+        torch.manual_seed(m["torch_seed"])
+        return TensorConvolutionTrainLayer(m["N"], m["r"], m["patches"], m["pixels"], output_shape=m["C"],
+                                           convolution_bond=m["CB"]).to(DEV).tensor_network
+    tn = fresh()
+    assert len(tn.train_nodes) == m["nodes"]
+    yp = tn.forward(x, to_tensor=True)
+    assert G.rel_err(yp, d[p + "forward"]) < 1e-10, m
+    _, gr, H = _loss(m["loss"]).forward(yp, y)
+    for k, node in enumerate(tn.train_nodes):
+        A, b = tn.get_A_b(node, gr, H)
+        assert G.rel_err(b.reshape(-1), d[p + f"b{k}"]) < 1e-9, (m, node.name)
+        v = G.T(d[p + f"v{k}"], DEV)
+        assert G.rel_err(A.reshape(v.numel(), v.numel()) @ v, d[p + f"Av{k}"]) < 1e-9, (m, node.name)
+        assert G.rel_err(tn.matvec(node, v.reshape(node.tensor.shape), H).reshape(-1), d[p + f"Av{k}"]) < 1e-9, (m, node.name)
+    tn2, losses = fresh(), []
+    assert tn2.accumulating_swipe(x, y, _loss(m["loss"]), batch_size=32, num_swipes=1, method="ridge_cholesky", eps=1.0,
+                                  eps_decay=0.5, loss_callback=lambda NS, n, l: losses.append(l), disable_tqdm=True)
+    ref = d[p + "chol_losses"]
+    assert len(losses) == len(ref) and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(losses, ref)), m
+    assert G.rel_err(tn2.forward(x, to_tensor=True), d[p + "chol_forward"]) < 1e-5, m
+    tn3, losses = fresh(), []
+    torch.manual_seed(m["torch_seed"] + 5)
+    assert tn3.lanczos_swipe(x, y, _loss(m["loss"]), batch_size=32, num_swipes=1, max_iter=2, tol=1e-6,
+                             loss_callback=lambda l: losses.append(l))
+    ref = d[p + "lanczos_losses"]
+    assert len(losses) == len(ref) and all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(losses, ref)), m
+    assert G.rel_err(tn3.forward(x, to_tensor=True), d[p + "lanczos_forward"]) < 1e-4, m
+
+
+@gpu
+@pytest.mark.parametrize("case", _random_conv_cases())
+def test_random_conv_golden(case):
+    check_random_conv(case, DEV)

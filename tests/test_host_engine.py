@@ -47,6 +47,11 @@ def test_estimators_host_logic(name, api):
     (api.test_tnml_fit_golden if name.startswith("tnml_") else api.test_ttreg_fit_golden)(name)
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_random_conv_host_logic(case, cpu_kernels):
+    conv.check_random_conv(case, "cpu")
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_random_swipes_host_logic(case, api):
     api.test_random_swipe_golden(case)
