@@ -180,8 +180,11 @@ class GramWorkspace:
         if nbytes < 0:
             raise _lib.TTKError("ttk_gram_ws_bytes: invalid extents")
         self.nbytes = int(nbytes)
-        self.buf = torch.empty((self.nbytes + 7) // 8, dtype=F64, device=device)
         self.gsize = gram_gsize(int(rl), int(p), int(rr), bool(sym))
+        # room for a right-hand side right behind the compressed Gram, whatever the sample count: a
+        # multi-rank run sends [Gram | b] as one message and every rank must lay it out alike
+        self.tail = int(rl) * int(p) * int(rr)
+        self.buf = torch.empty(max((self.nbytes + 7) // 8, self.gsize + self.tail), dtype=F64, device=device)
         mp = int(rl) * (int(rl) + 1) // 2 if sym else int(rl) * int(rl)
         self.mppad = (mp + 47) // 48 * 48    # leading extent of the compressed Gram [mppad][pairs(p,q)][nrpad]
         self.pair_rep = None                 # feature-pair classes of the last Gram computed into it

@@ -76,23 +76,32 @@ class Shard:
         slices G[:, rep, :] travel (packed, summed, copied back to every member of their class): at
         the headline shape 24.5 MB instead of 46.8 MB.  The classes must be the common ones
         (common_pair_classes), or ranks would disagree about the message size.  Without classes
-        the message is the workspace itself: `b` rides in the scratch right behind the Gram."""
+        the message is the workspace itself: `b` rides in the `tail` doubles the workspace keeps
+        right behind the Gram (a workspace without such a tail is copied into a fresh message)."""
         G = ws.compressed
         rep = getattr(ws, "pair_rep", None)
         if self.world == 1:
             return G
         nb = 0 if b is None else b.numel()
         if rep is None:
+            # Whether `b` rides behind the Gram in the workspace must not depend on anything a rank measures on
+            # its own shard (the scratch size does: shards differ by one sample), or ranks would issue different
+            # collectives.  `tail` is set from the site's extents alone, which every rank shares.
+            if not nb:
+                self.allreduce_sum_(G)
+                return G
             buf = getattr(ws, "buf", None)
-            if nb and buf is not None and buf.numel() >= G.numel() + nb and buf.data_ptr() == G.data_ptr():
+            if buf is not None and getattr(ws, "tail", 0) >= nb and buf.data_ptr() == G.data_ptr():
                 msg = buf[:G.numel() + nb]
                 msg[G.numel():].copy_(b.reshape(-1))
                 self.allreduce_sum_(msg)
-                b.copy_(msg[G.numel():].reshape(b.shape))
             else:
-                self.allreduce_sum_(G)
-                if nb:
-                    self.allreduce_sum_(b)
+                msg = torch.empty(G.numel() + nb, dtype=G.dtype, device=G.device)
+                msg[:G.numel()].copy_(G.reshape(-1))
+                msg[G.numel():].copy_(b.reshape(-1))
+                self.allreduce_sum_(msg)
+                G.reshape(-1).copy_(msg[:G.numel()])
+            b.copy_(msg[G.numel():].reshape(b.shape))
             return G
         nx = len(rep)
         reps = sorted(set(int(v) for v in rep))

@@ -323,10 +323,11 @@ class LocalProblem:
             out = ops.kr_rows(*a) if out is None else ops.kr_rows(*a, out=out)
         return out
 
-    def dense_gram(self, H, chunk_bytes=1 << 30):
-        """A (D,D) = sum_s J^T H J from explicit rows in sample chunks (ttk_gemm_tn_f64)."""
+    def dense_gram(self, H, chunk_bytes=1 << 30, out=None):
+        """A (D,D) = sum_s J^T H J from explicit rows in sample chunks (ttk_gemm_tn_f64); added to `out`
+        (a zeroed (D,D) buffer of the caller's) when given."""
         D, C = self.D, self.C
-        A = torch.zeros((D, D), dtype=F64, device=H.device)
+        A = torch.zeros((D, D), dtype=F64, device=H.device) if out is None else out
         step = max(1, int(chunk_bytes // (8 * C * D)))
         for lo in range(0, self.S, step):
             hi = min(self.S, lo + step)

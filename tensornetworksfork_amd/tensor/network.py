@@ -378,11 +378,15 @@ class TensorNetwork:
             front["ws"] = ws
             front["gen"] = ws.generation   # the workspace is shared: a later Gram into it outdates this front
         else:
-            # several Khatri-Rao terms (conv bond) or a conv node: explicit rows, library GEMM, library solve
-            A_f = lp.dense_gram(H)
-            if d.sharded:
-                self._shard.allreduce_sum_(A_f)
-                self._shard.allreduce_sum_(b)
+            # several Khatri-Rao terms (conv bond) or a conv node: explicit rows and the dense Gram kernel
+            if d.sharded:   # [dense Gram | RHS] laid out as one buffer: one all-reduce per core update here too
+                msg = torch.zeros(lp.D * lp.D + b.numel(), dtype=b.dtype, device=b.device)
+                A_f = lp.dense_gram(H, out=msg[:lp.D * lp.D].view(lp.D, lp.D))
+                msg[lp.D * lp.D:].copy_(b.reshape(-1))
+                self._shard.allreduce_sum_(msg)
+                front["b"] = msg[lp.D * lp.D:].view(b.shape)
+            else:
+                A_f = lp.dense_gram(H)
             front["A_f"] = A_f
         return front
 

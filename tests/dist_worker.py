@@ -2,6 +2,8 @@
 
 mode "cpu": partition + collective logic on CPU tensors under gloo; the local Gram / RHS of
             each shard comes from the oracle, the sharded sum must equal the full-data result.
+mode "cpu_engine": the package's host logic over the torch stand-ins of the kernels
+            (tests/_kernel_standins.py) on CPU tensors: sharded conv / CPD / sum-of-networks sweeps.
 mode "gpu": the real engine, every rank on cuda:0 under gloo (device tensors staged through
             the host); a sharded sweep must reproduce the single-process sweep.
 """
@@ -13,6 +15,102 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def _same_on_all_ranks(sh, tensors):
+    ok = True
+    for t in tensors:
+        ref = t.clone()
+        sh.broadcast_(ref)
+        ok &= bool(torch.equal(ref, t))
+    return ok
+
+
+def _more_gpu_cases(sh, dev):
+    """What a sample-sharded run of the image configurations and the estimators' other model types
+    goes through: conv tensor trains (no convolution bond / bond 2, float64 / float32) under the
+    matrix-free sweeps, a CPD layer and a type-I sum of networks under accumulating_swipe (dense
+    Gram: [A | b] in one message), and shards so small that their workspaces differ in size.
+    Each case: sharded == single process, and bit-identical nodes on every rank."""
+    import scipy.sparse.linalg as spla
+    from tensornetworksfork_amd.tensor import layers as Lm, network as Nm
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction, XEAutogradBregman
+    from tests._net_cases import net_builders
+    ok = True
+    g = torch.Generator().manual_seed(21)
+
+    def compare(make, run, tol, what):
+        nonlocal ok
+        outs = []
+        for shard in (False, True):
+            layer = make().to(dev)
+            tn = layer.tensor_network
+            if shard:
+                tn.distribute(sh)
+            torch.manual_seed(300)
+            run(tn)
+            outs.append([n.tensor.clone() for n in tn.train_nodes])
+        for a, b in zip(*outs):
+            err = ((a.double() - b.double()).norm() / a.double().norm()).item()
+            if not err < tol:
+                print(f"[rank {sh.rank}] {what}: sharded differs from single process by {err:.3e}", flush=True)
+                ok = False
+        if not _same_on_all_ranks(sh, outs[1]):
+            print(f"[rank {sh.rank}] {what}: nodes differ between ranks", flush=True)
+            ok = False
+
+    # conv tensor trains, 17 patches (the features-first route of the image configurations)
+    S, C = 203, 3
+    for dt, cb, sweep, tol in ((torch.float64, -1, "lanczos", 1e-9), (torch.float64, 2, "minres", 1e-9),
+                               (torch.float64, 2, "ridge", 1e-9), (torch.float32, -1, "lanczos", 2e-3),
+                               (torch.float32, -1, "ridge", 1e-4)):
+        x = (torch.rand(S, 17, 5, generator=g) * 0.5).to(dt).to(dev)
+        y = torch.nn.functional.one_hot(torch.randint(0, C + 1, (S,), generator=g), C + 1).to(torch.float64).to(dev)
+
+        def make(dt=dt, cb=cb):
+            torch.set_default_dtype(dt)
+            try:
+                torch.manual_seed(11)
+                return Lm.TensorConvolutionTrainLayer(3, 4, 17, 5, output_shape=C, convolution_bond=cb)
+            finally:
+                torch.set_default_dtype(torch.float64)
+
+        def run(tn, sweep=sweep, x=x, y=y):
+            bf = XEAutogradBregman(w=1.0)
+            if sweep == "lanczos":
+                tn.lanczos_swipe(x, y, bf, batch_size=64, num_swipes=1, max_iter=3)
+            elif sweep == "minres":
+                tn.scipy_swipe(x, y, bf, spla.minres, batch_size=64, num_swipes=1, max_iter=4)
+            else:
+                tn.accumulating_swipe(x, y, bf, batch_size=64, num_swipes=1, method="ridge_cholesky", eps=0.1)
+        compare(make, run, tol, f"conv {dt} cb={cb} {sweep}")
+
+    # CPD layer and type-I sums under the Gauss-Newton sweep
+    builders = net_builders(Lm, Nm)
+    for name, kind, Cn in (("cpd_c1", "square", 1), ("cpd_c2", "xe", 2), ("sum_tt_type1_c1", "square", 1),
+                           ("sum_cpd_type1_c2", "xe", 2), ("ttlinear_c2", "xe", 2)):
+        S = 157
+        x = (torch.rand(S, 6, generator=g) * 2 - 1).to(dev)
+        if kind == "xe":
+            y = torch.nn.functional.one_hot(torch.randint(0, Cn + 1, (S,), generator=g), Cn + 1).to(torch.float64).to(dev)
+        else:
+            y = torch.randn(S, Cn, generator=g).to(dev)
+
+        def run(tn, kind=kind, x=x, y=y):
+            bf = XEAutogradBregman(w=1.0) if kind == "xe" else SquareBregFunction()
+            tn.accumulating_swipe(x, y, bf, batch_size=50, num_swipes=1, method="ridge_cholesky", eps=0.1)
+        compare(builders[name], run, 1e-9, name)
+
+    # shards of 18 and 19 samples with generic features: the Gram workspaces of the two ranks differ in
+    # size, the message they exchange must not
+    S = 37
+    xs = [(torch.rand(S, 6, generator=g) * 2 - 1).to(dev) for _ in range(4)]
+    y = torch.randn(S, 1, generator=g).to(dev)
+
+    def run(tn):
+        tn.accumulating_swipe(xs, y, SquareBregFunction(), batch_size=16, num_swipes=1, method="ridge_cholesky", eps=0.5)
+    compare(lambda: Lm.TensorTrainLayer(4, 16, 6, output_shape=1, constrict_bond=False, seed=5), run, 1e-9, "tiny uneven shards")
+    return ok
 
 
 def main():
@@ -72,8 +170,26 @@ def main():
         want = PlainWS.compressed.clone()
         sh.allreduce_sum_(want)
         bvec = torch.arange(5, dtype=torch.float64) * (sh.rank + 2)
+        sh.allreduce_gram_(PlainWS, bvec)                # no `tail`: packed into a fresh message
+        ok &= bool(torch.equal(PlainWS.compressed, want)) and bool(torch.equal(bvec, bwant))
+        PlainWS.tail = 5                                 # room behind the Gram on every rank: sent in place
+        PlainWS.buf[:210] = torch.arange(210, dtype=torch.float64) * (sh.rank + 1)
+        bvec = torch.arange(5, dtype=torch.float64) * (sh.rank + 2)
         sh.allreduce_gram_(PlainWS, bvec)
         ok &= bool(torch.equal(PlainWS.compressed, want)) and bool(torch.equal(bvec, bwant))
+        ok &= bool(torch.equal(PlainWS.buf[210:215], bwant))
+    elif mode == "cpu_engine":
+        # the real host logic (engines, sweeps, sharding) over the torch stand-ins of the kernels, on CPU tensors
+        from tensornetworksfork_amd import ops
+        from tests import _kernel_standins
+
+        class _Patch:
+            @staticmethod
+            def setattr(obj, name, value):
+                setattr(obj, name, value)
+        _kernel_standins.install(_Patch)
+        assert ops.gram is _kernel_standins.gram
+        ok &= _more_gpu_cases(sh, "cpu")
     else:
         from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
         from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
@@ -132,6 +248,7 @@ def main():
                 ref = t.clone()
                 sh.broadcast_(ref)
                 ok &= bool(torch.equal(ref, t))
+        ok &= _more_gpu_cases(sh, dev)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if sh.rank == 0:

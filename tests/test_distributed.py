@@ -22,6 +22,10 @@ def test_sharded_sums_world2_cpu(tmp_path):
     _launch("cpu", tmp_path, 29531)
 
 
+def test_sharded_engine_world2_cpu(tmp_path):
+    _launch("cpu_engine", tmp_path, 29533)
+
+
 @pytest.mark.gpu
 def test_sharded_sweeps_world2_gpu(tmp_path):
     _launch("gpu", tmp_path, 29532)
