@@ -14,7 +14,11 @@ all-reduce of [compressed Gram | RHS] precedes the replicated solve.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the Gram kernel (HIP events recorded on its
 launch stream inside the timed region); `cpu_baseline` is the CPU oracle (oracle/tt_oracle.py)
-timed on the host cores on a bounded sample; `variants.cg` is the matrix-free CG path (N = 1).
+timed on the host cores on a bounded sample; `variants.cg` / `variants.lanczos` are the matrix-free
+paths on the same model, `variants.sweep` a whole first swipe of fit() (also `sweep_updates_per_sec`),
+`variants.mnist_lanczos*` / `variants.cifar_lanczos_f32` one lanczos_swipe pass over a conv tensor
+train at the image scripts' sizes, each with the roofline of its dominant kernel and, as parity, the
+size-independent identities its kernels must satisfy (N = 1).
 """
 import argparse
 import json
@@ -31,6 +35,7 @@ if ROOT not in sys.path:
 
 N_SITES, BOND, DEGREE, S_ALL, N_FEAT = 16, 32, 5, 60000, 16
 FP64_MFMA_PEAK_TFLOPS = 78.6    # MI355X dense fp64 matrix peak (v_mfma_f64_16x16x4: 64 cycles/SIMD at 2.4 GHz)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_16x16x4: 32 cycles/SIMD)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -121,6 +126,192 @@ def cg_variant(device, F, y, steps):
                          "algorithmic_bytes_per_launch": it_bytes,
                          "hbm_gbs": it_bytes / (avg_ms * 1e-3) * 1e-9,
                          "hbm_frac": it_bytes / (avg_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, "traffic": None}}
+
+
+def _timed_kernel(which, fn):
+    """Run fn() with HIP events armed around every launch of one kernel (ttk_gram_timing: 2 the fused
+    matrix-free product, 3 the features-first right-hand side, 4 the resident right-environment step);
+    returns the launch durations in ms."""
+    from tensornetworksfork_amd import ops
+    ops.gram_timing(which)
+    torch.cuda.synchronize()
+    fn()
+    torch.cuda.synchronize()
+    ms = ops.gram_timing_read()
+    ops.gram_timing(0)
+    return ms
+
+
+def _mfma_roofline(kernel, flops, ms_list, peak, bytes_=None):
+    avg = float(np.mean(ms_list)) if ms_list else float("nan")
+    tfl = flops / (avg * 1e-3) * 1e-12
+    out = {"kernel": kernel, "bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
+           "launches": len(ms_list), "avg_launch_us": avg * 1e3, "flops_per_launch": flops, "traffic": None}
+    if bytes_ is not None:
+        out["algorithmic_bytes_per_launch"] = bytes_
+        out["hbm_gbs"] = bytes_ / (avg * 1e-3) * 1e-9
+        out["hbm_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+    return out
+
+
+def lanczos_variant(device, F, y, steps=8, max_iter=100):
+    """lanczos_swipe (tensor/network.py:709-832) on middle sites of the timed model: one product
+    v -> J^T H J v (the fused one-pass kernel) and one fused vector kernel per iteration, the exit test on
+    the device, the tridiagonal solve and x0 + V y in two more launches."""
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    layer = make_model(device)
+    tn = layer.tensor_network
+    all_nodes = tn.train_nodes
+    try:
+        tn.train_nodes = tn.main_nodes[2:3]
+        torch.manual_seed(0)
+        tn.lanczos_swipe(F, y, SquareBregFunction(), batch_size=512, max_iter=max_iter, tol=1e-6)   # warm-up
+        tn.train_nodes = tn.main_nodes[3:3 + steps]
+        holder = {}
+
+        def run():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tn.lanczos_swipe(F, y, SquareBregFunction(), batch_size=512, max_iter=max_iter, tol=1e-6)
+            torch.cuda.synchronize()
+            holder["dt"] = time.perf_counter() - t0
+        mv_ms = _timed_kernel(2, run)
+    finally:
+        tn.train_nodes = all_nodes
+    S, D = F[0].shape[0], BOND * (DEGREE + 1) * BOND
+    per = holder["dt"] / steps
+    return {"value": 1.0 / per, "unit": "core-updates/s", "ms_per_step": per * 1e3, "steps": steps, "max_iter": max_iter,
+            "tol": 1e-6, "products_per_update": len(mv_ms) / steps, "us_per_iteration": per * 1e6 / (len(mv_ms) / steps),
+            "roofline": _mfma_roofline("matvec_fused_kernel<8,3,0>", 4.0 * S * D, mv_ms, FP64_MFMA_PEAK_TFLOPS,
+                                       S * (BOND + DEGREE + 1 + BOND + 1) * 8.0)}
+
+
+def _conv_problem(device, S, patches, pixels, bond, dtype, conv_bond):
+    """Synthetic data of the image scripts' shapes (image_convolution_lanczos_MNIST.py:29-32, CIFAR_lanczos_swipe.py:
+    35-38: unfolded patches with a zero row / column and a corner 1), labels from a linear teacher, the scripts' model
+    (3 carriages, 9 trained logits) and their loss scaling."""
+    from tensornetworksfork_amd.tensor.bregman import XEAutogradBregman
+    from tensornetworksfork_amd.tensor.layers import TensorConvolutionTrainLayer
+    torch.set_default_dtype(dtype)
+    try:
+        torch.manual_seed(5)
+        layer = TensorConvolutionTrainLayer(num_carriages=3, bond_dim=bond, num_patches=patches, patch_pixels=pixels,
+                                            output_shape=9, convolution_bond=conv_bond).to(device)
+    finally:
+        torch.set_default_dtype(torch.float64)
+    g = torch.Generator(device=device).manual_seed(6)
+    x = torch.randn(S, patches, pixels, generator=g, dtype=dtype, device=device)
+    x[:, -1, :] = 0.0
+    x[:, :, -1] = 0.0
+    x[:, -1, -1] = 1.0
+    teacher = torch.randn(patches * pixels, 10, generator=g, dtype=dtype, device=device)
+    y = torch.nn.functional.one_hot((x.reshape(S, -1) @ teacher).argmax(dim=1), 10).to(torch.float64)
+    with torch.inference_mode():
+        w = 1.0 / layer.tensor_network.forward(x[:64].contiguous(), to_tensor=True).std().item()
+    return layer, x, y, XEAutogradBregman(w=w)
+
+
+def _conv_identities(tn, x, y, bf):
+    """Size-independent identities that tie the kernels on every train node's route to each other (no CPU answer
+    exists at these sizes): linearity f(node + v) - f(node) = J v, adjointness <b, v> = <g, J v>, symmetry
+    <u, A v> = <A u, v> and factorisation <v, A v> = sum_s (Jv)^T H (Jv) of A = J^T H J.  Worst relative residual
+    of each over the nodes."""
+    f64 = torch.float64
+    f0 = tn.forward(x, to_tensor=True).to(f64)
+    _, g, H = bf.forward(f0, y)
+    g, H = g.to(f64), H.to(f64)
+    gen = torch.Generator(device=x.device).manual_seed(7)
+    worst = {"linearity": 0.0, "adjoint": 0.0, "symmetry": 0.0, "factorisation": 0.0}
+    for node in tn.train_nodes:
+        dt = node.tensor.dtype
+        scale = node.tensor.abs().max().item()
+        v = (torch.randn(node.tensor.shape, generator=gen, device=x.device, dtype=f64) * scale).to(dt)
+        u = (torch.randn(node.tensor.shape, generator=gen, device=x.device, dtype=f64) * scale).to(dt)
+        d, lp = tn._local(node)
+        Jv = lp.jv(tn._engine.to_canon(node, v)).to(f64)
+        old = node.tensor
+        node.tensor = old + v
+        f1 = tn.forward(x, to_tensor=True).to(f64)
+        node.tensor = old
+        tn.forward(x)
+        b = tn.get_b(node, g).to(f64)
+        Av, Au = tn.matvec(node, v, H).to(f64), tn.matvec(node, u, H).to(f64)
+        quad = torch.einsum('sc,scd,sd->', Jv, H, Jv)
+        res = {"linearity": ((f1 - f0) - Jv).norm() / Jv.norm(),
+               "adjoint": abs((b * v.to(f64)).sum() - (g * Jv).sum()) / (g.norm() * Jv.norm()),
+               "symmetry": abs((u.to(f64) * Av).sum() - (v.to(f64) * Au).sum()) / (Av.norm() * u.to(f64).norm()),
+               "factorisation": abs((v.to(f64) * Av).sum() - quad) / abs(quad)}
+        for k, r in res.items():
+            worst[k] = max(worst[k], float(r.item()))
+    return worst
+
+
+def conv_lanczos_variant(device, S, patches, pixels, bond, dtype, conv_bond, tol, max_iter=12, repeats=3, what="",
+                         shard=False):
+    """One lanczos_swipe pass (tensor/network.py:709-832) over the six train nodes (filters C_i, carriages A_i) of a
+    conv tensor train at an image script's size.  max_iter = 12: a filter node has `pixels` unknowns, beyond that
+    many iterations its Krylov space is exhausted and the reference's own tridiagonal solve returns rounding noise."""
+    layer, x, y, bf = _conv_problem(device, S, patches, pixels, bond, dtype, conv_bond)
+    tn = layer.tensor_network
+    world = 1
+    if shard:   # every rank builds the same problem from the same seeds and works on its own block of samples
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        tn.distribute("auto")
+        parity = None
+    else:
+        parity = _conv_identities(tn, x, y, bf)
+        parity.update({"tolerance": tol, "ok": bool(max(parity.values()) <= tol),
+                       "what": "worst relative residual over the six train nodes of: f(node+v)-f(node) = Jv, "
+                               "<b,v> = <g,Jv>, <u,Av> = <Au,v>, <v,Av> = sum (Jv)^T H (Jv)"})
+    nodes0 = [n.tensor.clone() for n in tn.train_nodes]
+    stamps = []
+
+    def block(NS, node):
+        torch.cuda.synchronize()
+        stamps.append((node.name, time.perf_counter()))
+
+    sweeps, per_node = [], {}
+    for rep in range(repeats + 1):
+        for n, t in zip(tn.train_nodes, nodes0):
+            n.tensor = t.clone()
+        stamps.clear()
+        torch.manual_seed(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = tn.lanczos_swipe(x, y, bf, batch_size=512, num_swipes=1, max_iter=max_iter, block_callback=block)
+        assert ok
+        if rep:   # the first pass warms caches and workspaces up
+            sweeps.append(stamps[-1][1] - t0)
+            prev = t0
+            for name, t in stamps:
+                per_node.setdefault(name, []).append((t - prev) * 1e3)
+                prev = t
+    sweep_ms = float(np.mean(sweeps)) * 1e3
+    node_ms = {k: float(np.mean(v)) for k, v in per_node.items()}
+    # the dominant kernels, on the middle carriage alone so that every timed launch has one shape
+    mid = [n for n in tn.train_nodes if n in tn.main_nodes][1]
+    rl, p, rr = bond, patches, bond
+    all_nodes = tn.train_nodes
+    roofs = []
+    try:
+        tn.train_nodes = [mid]
+        for which, kernel in ((3, "rhs_feature_kernel"), (4, "env_right_resident_kernel")):
+            torch.manual_seed(1)
+            ms = _timed_kernel(which, lambda: tn.lanczos_swipe(x, y, bf, batch_size=512, num_swipes=1, max_iter=max_iter))
+            peak = FP32_MFMA_PEAK_TFLOPS if dtype == torch.float32 else FP64_MFMA_PEAK_TFLOPS
+            if ms:
+                roofs.append(_mfma_roofline(kernel + ("<float>" if dtype == torch.float32 else "<double>"),
+                                            2.0 * ((S + world - 1) // world) * rl * p * rr, ms, peak))
+    finally:
+        tn.train_nodes = all_nodes
+    iters = max_iter + 1      # products per node: the residual of the start vector + one per iteration
+    return {"workload": what, "samples": S, "ranks": world, "patches": patches, "pixels": pixels, "bond": bond, "conv_bond": conv_bond,
+            "dtype": "f32" if dtype == torch.float32 else "f64", "max_iter": max_iter, "sweep_ms": sweep_ms,
+            "node_updates_per_sec": len(node_ms) / (sweep_ms * 1e-3), "samples_per_sec_sweep": S / (sweep_ms * 1e-3),
+            "node_ms": node_ms, "us_per_krylov_iteration": {k: v * 1e3 / iters for k, v in node_ms.items()},
+            "roofline": roofs[0] if roofs else None, "roofline_env": roofs[1] if len(roofs) > 1 else None,
+            "parity": parity, "repeats": repeats}
 
 
 def parity_and_cpu_baseline(device, F, y, sites=(6, 7, 8), eps=1.0):
@@ -344,10 +535,31 @@ def main():
         probe["gram_frac_of_dgemm"] = achieved / probe["tflops"]
         out["roofline"]["dgemm_probe"] = probe
     if rank == 0 and world == 1 and not args.no_variants:
-        out["variants"] = {"cg": cg_variant(device, F, y, steps=10),
-                           "sweep": sweep_variant(device, F, y, F_val, y_val)}
+        sweep = sweep_variant(device, F, y, F_val, y_val)
+        out["sweep_updates_per_sec"] = sweep["core_updates_per_sec"]     # whole first swipe of fit(): 31 updates, edge sites incl.
+        out["variants"] = {"cg": cg_variant(device, F, y, steps=10), "sweep": sweep,
+                           "lanczos": lanczos_variant(device, F, y)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["parity"], out["cpu_baseline"] = parity_and_cpu_baseline(device, F, y)
+    if not args.no_variants:
+        # image-shaped conv tensor trains: on one GPU the three variants; with N > 1 every rank takes its sample
+        # shard of the cfg-5 model (what CIFAR_lanczos_swipe.py would run on the node), rank 0 reports
+        del F, y, F_val, y_val, layer, tn
+        torch.cuda.empty_cache()
+        f64, f32 = torch.float64, torch.float32
+        v = out.setdefault("variants", {})
+        if world == 1:
+            v["mnist_lanczos"] = conv_lanczos_variant(
+                device, 54000, 50, 17, 24, f64, -1, 1e-9,
+                what="cfg4 shape: 3 carriages, bond 24, 50 patches x 17 pixels, 9 logits, 54000 samples, fp64 "
+                     "(image_convolution_lanczos_MNIST.py:29-32,76-92), no convolution bond")
+            v["mnist_lanczos_cb4"] = conv_lanczos_variant(
+                device, 54000, 50, 17, 10, f64, 4, 1e-9,
+                what="the MNIST script's own model: bond 10, convolution bond 4 (image_convolution_lanczos_MNIST.py:76)")
+        v["cifar_lanczos_f32"] = conv_lanczos_variant(
+            device, 50000, 65, 49, 48, f32, -1, 2e-5, shard=world > 1,
+            what="cfg5 shape: 3 carriages, bond 48, 65 patches x 49 pixels, 9 logits, 50000 samples, float32 nodes and "
+                 f"data (CIFAR_lanczos_swipe.py:35-38,68-108); samples sharded over {world} rank(s)")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -123,7 +123,10 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
  * library runs on until the process ends) instead of a caller workspace; the call allocates and
  * frees nothing.  Extents whose ttk_rhs_ws_bytes exceeds that size return TTK_EWORKSPACE and launch
  * nothing.  All calls on one GPU share the array: calls that overlap on one GPU (different
- * streams) race; calls on one stream are ordered and safe. */
+ * streams) race; calls on one stream are ordered and safe.  The array's device address is looked up
+ * once per device (hipGetSymbolAddress, not a capturable operation): ttk_rhs_static_max_bytes() does
+ * it for the current device, so call it once per device before a capture; otherwise the first
+ * ttk_rhs_static_f64 on that device does.  The device must be current when either is called. */
 int64_t ttk_rhs_static_max_bytes(void);
 int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const double* g, double* b,
                        int64_t S, int C, int rl, int p, int rr, int accumulate, void* stream);
@@ -225,7 +228,16 @@ int ttk_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, i
  * ttk_lanczos_update_f64: iteration j >= 1 of the Lanczos recurrence of lanczos_solver
  * (tensor/network.py:796-824) with w = A v_cur on entry:  w -= betas[j-1] v_prev (skipped when
  * v_prev is NULL: the reference's zero vector of the first iteration), alphas[j-1] = <w,v_cur>,
- * w -= alphas[j-1] v_cur, betas[j] = ||w||, v_next = w / betas[j].
+ * w -= alphas[j-1] v_cur, betas[j] = ||w||, v_next = w / betas[j].  The reference leaves its loop
+ * when betas[j] < tol (network.py:813): the kernel then writes j to stop[0] (device, 0.0 before the
+ * first iteration), and every later call is a no-op once stop[0] != 0, so the host may queue
+ * iterations ahead and look at stop[0] only now and then.
+ *
+ * ttk_lanczos_finish_f64: the end of that solver (network.py:815-824).  m = stop[0] if set, else
+ * m_run (the iterations queued); T_m y = betas[0] e_1 with T_m = tridiag(betas[1..m), alphas[0..m),
+ * betas[1..m)) by Gaussian elimination with partial pivoting (torch.linalg.solve on the dense T_m in
+ * the reference), then x = x0 + sum_{j<m} y[j] V[j,:] over the rows of the basis V (m_cap+1 rows of
+ * stride ldv >= D; row j = v_{j+1}): one pass over the basis, no copy of it.  ws: ttk_lanczos_finish_ws_bytes(m_cap).
  *
  * ttk_minres_update_f64: the vector half of one iteration of scipy.sparse.linalg.minres (no shift, no
  * preconditioner; the other solver scipy_swipe is used with, CIFAR_minres.py:112 through
@@ -249,7 +261,11 @@ int64_t ttk_minres_update_ws_bytes(int64_t D);
 int ttk_minres_update_ws_f64(double* y, double* r1, double* r2, double* v, double* w, double* w2, double* x, double* state,
                              int64_t D, void* ws, int64_t ws_bytes, void* stream);
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
-                           double* betas, int j, int64_t D, void* stream);
+                           double* betas, int j, int64_t D, double tol, double* stop, void* stream);
+int64_t ttk_lanczos_finish_ws_bytes(int m_cap);
+int ttk_lanczos_finish_f64(const double* V, int64_t ldv, const double* alphas, const double* betas, const double* stop,
+                           int m_run, int m_cap, const double* x0, double* x, int64_t D, void* ws, int64_t ws_bytes,
+                           void* stream);
 /* out[row] = <J[row, :], v> for explicit Jacobian rows J (rows = S*C, D entries each): the J v of a narrow node
  * (a conv filter node, tensor/network.py:101-113 with 788) in one pass over J at memory speed. */
 int ttk_rows_dot_f64(const double* J, const double* v, double* out, int64_t rows, int D, void* stream);

@@ -75,7 +75,9 @@ SIGNATURES = {
     "ttk_rhs_feature_mm32": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_dense_scale_f64": (_int, [_c_dp, _int, _c_dp, _c_dp]),
     "ttk_chol_prepare_dense_f64": (_int, [_c_dp, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),
-    "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _c_dp]),
+    "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _dbl, _c_dp, _c_dp]),
+    "ttk_lanczos_finish_ws_bytes": (_i64, [_int]),
+    "ttk_lanczos_finish_f64": (_int, [_c_dp, _i64, _c_dp, _c_dp, _c_dp, _int, _int, _c_dp, _c_dp, _i64, _c_dp, _i64, _c_dp]),
     "ttk_rows_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _c_dp]),
     "ttk_rows_matvec_ws_bytes": (_i64, [_i64, _int, _int]),
     "ttk_rows_matvec_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp, _i64, _c_dp]),

@@ -24,6 +24,19 @@ static inline int ttk_launch_status() { return hipGetLastError() == hipSuccess ?
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Dynamic LDS above 64 KiB has to be allowed once per kernel and per device (the attribute belongs to the
+// device's copy of the code object).  flags: one per device, owned by the call site; threads that race here
+// set the same attribute twice, nothing else is shared.
+#define TTK_MAX_DEVICES 64
+static bool allow_big_lds(const void* fn, bool* flags, int bytes) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TTK_MAX_DEVICES) return false;
+  if (flags[dev]) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  flags[dev] = true;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // Environment step as a GEMM with an on-the-fly left operand.
 //   rows  = (s,c) pairs (M = S*C), contraction index k = (e_idx, p_idx), columns n.
@@ -594,13 +607,9 @@ static int env_fast_launch(bool left, const double* E, const double* X, const do
         (const void*)env_reg_kernel<false, 3, 4>, (const void*)env_reg_kernel<false, 4, 4>,
         (const void*)env_reg_kernel<false, 1, 8>, (const void*)env_reg_kernel<false, 2, 8>,
         (const void*)env_reg_kernel<false, 3, 8>, (const void*)env_reg_kernel<false, 4, 8>};
-    static bool reg_lds_set = false;
-    if (!reg_lds_set) {
-      for (int v = 0; v < 16; ++v)
-        if (hipFuncSetAttribute(regv[v], hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-          return TTK_ELAUNCH;
-      reg_lds_set = true;
-    }
+    static bool reg_lds_set[16][TTK_MAX_DEVICES];
+    for (int v = 0; v < 16; ++v)
+      if (!allow_big_lds(regv[v], reg_lds_set[v], 80 * 1024)) return TTK_ELAUNCH;
     const size_t rlds = (size_t)e * p * (nt * 16) * sizeof(double);   // <= 32 * 8 * 64 * 8 = 128 KiB ... checked below
     if (rlds <= 80 * 1024) {
       int Mi = (int)M;
@@ -611,17 +620,13 @@ static int env_fast_launch(bool left, const double* E, const double* X, const do
       return ttk_launch_status();
     }
   }
-  static bool big_lds_set = false;   // dynamic LDS above 64 KiB has to be allowed once per kernel
+  static bool big_lds_set[8][TTK_MAX_DEVICES];
   const void* variants[8] = {(const void*)env_fast_kernel<true, 1>,  (const void*)env_fast_kernel<true, 2>,
                              (const void*)env_fast_kernel<true, 3>,  (const void*)env_fast_kernel<true, 4>,
                              (const void*)env_fast_kernel<false, 1>, (const void*)env_fast_kernel<false, 2>,
                              (const void*)env_fast_kernel<false, 3>, (const void*)env_fast_kernel<false, 4>};
-  if (!big_lds_set) {
-    for (int v = 0; v < 8; ++v)
-      if (hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-        return TTK_ELAUNCH;
-    big_lds_set = true;
-  }
+  for (int v = 0; v < 8; ++v)
+    if (!allow_big_lds(variants[v], big_lds_set[v], 80 * 1024)) return TTK_ELAUNCH;
   int Mi = (int)M;
   void* args[] = {(void*)&E, (void*)&X, (void*)&core, (void*)&out, (void*)&Mi, (void*)&C, (void*)&e, (void*)&p,
                   (void*)&n, (void*)&accumulate, (void*)&mode, (void*)&Rdot, (void*)&Hmul};
@@ -1777,15 +1782,9 @@ static int mvf_launch(int mode, const MvfDims& d, const double* L, const double*
                       const double* vsrc, const double* pold, double* pnew, double* cgst, const double* rho_part, int it,
                       int64_t S, int p, double* partial, double* pq_part, hipStream_t st) {
   mvf_fn_t fn = mode ? mvf_pick<1>(d.E4, d.TW) : mvf_pick<0>(d.E4, d.TW);
-  static mvf_fn_t allowed[16];   // dynamic LDS above 64 KiB has to be allowed once per kernel
-  static int nallowed = 0;
-  bool seen = false;
-  for (int k = 0; k < nallowed; ++k) seen |= allowed[k] == fn;
-  if (!seen) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return TTK_ELAUNCH;
-    if (nallowed < 16) allowed[nallowed++] = fn;
-  }
+  static bool allowed[2][2][8][TTK_MAX_DEVICES];
+  if (d.TW < 0 || d.TW > 7 || !allow_big_lds((const void*)fn, allowed[mode ? 1 : 0][d.E4 == 8 ? 1 : 0][d.TW], 150 * 1024))
+    return TTK_ELAUNCH;
   const bool timed = mvf_timing_begin(st);
   hipLaunchKernelGGL(fn, dim3((unsigned)d.nwg), dim3(512), d.lds, st, L, X, R, H, vsrc, pold, pnew, cgst, rho_part, d.nrp, it,
                      S, p, d.slab_len, d.W, partial, pq_part);
@@ -2012,8 +2011,10 @@ template <bool REG>
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict__ w, const double* __restrict__ v_prev,
                                                                const double* __restrict__ v_cur,
                                                                double* __restrict__ v_next, double* __restrict__ alphas,
-                                                               double* __restrict__ betas, int j, int64_t D) {
+                                                               double* __restrict__ betas, int j, int64_t D, double tol,
+                                                               double* __restrict__ stop) {
   __shared__ double red[16];
+  if (*stop != 0.0) return;      // an earlier iteration found beta < tol: the basis ends there
   const double bprev = betas[j - 1];
   double a, bj;
   if (REG) {
@@ -2068,6 +2069,7 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict
   if (threadIdx.x == 0) {
     alphas[j - 1] = a;
     betas[j] = bj;
+    if (bj < tol) *stop = (double)j;
   }
 }
 
@@ -2076,14 +2078,16 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(double* __restrict
 // written last:
 //   <0>  w -= beta[j-1] v_prev, partial <w, v_cur>            -> v_next[wg]
 //   <1>  alpha = sum of those (every workgroup, fixed order); w -= alpha v_cur, partial <w, w> -> v_next[LZW_WG + wg]
-//   lanczos_wide_scalars_kernel (one workgroup): alphas[j-1], betas[j] = sqrt(sum)
+//   lanczos_wide_scalars_kernel (one workgroup): alphas[j-1], betas[j] = sqrt(sum); the only writer of `stop`
 //   <2>  v_next = w / betas[j]
 #define LZW_WG 128
 template <int PHASE>
 __global__ __launch_bounds__(256) void lanczos_wide_kernel(double* __restrict__ w, const double* __restrict__ v_prev,
                                                             const double* __restrict__ v_cur, double* __restrict__ v_next,
-                                                            const double* __restrict__ betas, int j, int64_t D) {
+                                                            const double* __restrict__ betas, int j, int64_t D,
+                                                            const double* __restrict__ stop) {
   __shared__ double red[4];
+  if (*stop != 0.0) return;
   const int64_t per = ((D + LZW_WG - 1) / LZW_WG + 1) & ~(int64_t)1;
   const int64_t k0 = (int64_t)blockIdx.x * per, k1 = min(D, k0 + per);
   if (PHASE == 0) {
@@ -2117,13 +2121,85 @@ __global__ __launch_bounds__(256) void lanczos_wide_kernel(double* __restrict__ 
 }
 __global__ __launch_bounds__(256) void lanczos_wide_scalars_kernel(const double* __restrict__ v_next,
                                                                     double* __restrict__ alphas, double* __restrict__ betas,
-                                                                    int j) {
+                                                                    int j, double tol, double* __restrict__ stop) {
   __shared__ double red[4];
+  if (*stop != 0.0) return;
   const double a = block_sum_256(threadIdx.x < LZW_WG ? v_next[threadIdx.x] : 0.0, red);
   const double b = block_sum_256(threadIdx.x < LZW_WG ? v_next[LZW_WG + threadIdx.x] : 0.0, red);
   if (threadIdx.x == 0) {
     alphas[j - 1] = a;
     betas[j] = sqrt(b);
+    if (sqrt(b) < tol) *stop = (double)j;
+  }
+}
+
+// The end of a Lanczos-Galerkin step (tensor/network.py:815-824): with m = the iteration at which beta fell
+// below the tolerance (`stop`, 0: none did, then m = m_run), solve T_m y = beta_1 e_1 for the symmetric
+// tridiagonal T_m (diagonal alphas[0..m), off-diagonal betas[1..m)) by Gaussian elimination with partial
+// pivoting (the algorithm of LAPACK's dgtsv, which is what a dense LU of a tridiagonal matrix amounts to).
+// One thread does the O(m) recurrence on arrays of 5 m doubles: in LDS where they fit (`in_lds`), else in the
+// workspace.  y and m (as y[-1], i.e. ws[0]) are left in the workspace for lanczos_combine_kernel.
+__global__ __launch_bounds__(64) void lanczos_tridiag_kernel(const double* __restrict__ alphas, const double* __restrict__ betas,
+                                                              const double* __restrict__ stop, int m_run, int mcap,
+                                                              double* __restrict__ ws, int in_lds) {
+  extern __shared__ double tri_lds[];
+  const int m = *stop != 0.0 ? (int)*stop : m_run;
+  double* y = ws + 1;
+  double* a = in_lds ? tri_lds : ws + 1 + mcap;
+  double *d = a, *dl = a + mcap, *du = a + 2 * mcap, *du2 = a + 3 * mcap, *b = a + 4 * mcap;
+  for (int i = threadIdx.x; i < m; i += 64) {
+    d[i] = alphas[i];
+    b[i] = i == 0 ? betas[0] : 0.0;
+    if (i + 1 < m) dl[i] = du[i] = betas[i + 1];
+    du2[i] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[0] = (double)m;
+    for (int i = 0; i + 1 < m; ++i) {
+      if (fabs(d[i]) >= fabs(dl[i])) {
+        const double fact = dl[i] / d[i];
+        d[i + 1] -= fact * du[i];
+        b[i + 1] -= fact * b[i];
+      } else {
+        const double fact = d[i] / dl[i];
+        d[i] = dl[i];
+        const double t = d[i + 1];
+        d[i + 1] = du[i] - fact * t;
+        if (i + 2 < m) {
+          du2[i] = du[i + 1];
+          du[i + 1] = -fact * du[i + 1];
+        }
+        du[i] = t;
+        const double tb = b[i];
+        b[i] = b[i + 1];
+        b[i + 1] = tb - fact * b[i + 1];
+      }
+    }
+    b[m - 1] /= d[m - 1];
+    if (m > 1) b[m - 2] = (b[m - 2] - du[m - 2] * b[m - 1]) / d[m - 2];
+    for (int i = m - 3; i >= 0; --i) b[i] = (b[i] - du[i] * b[i + 1] - du2[i] * b[i + 2]) / d[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += 64) y[i] = b[i];
+}
+
+// x = x0 + sum_{j < m} y[j] V[j, :] over the rows of the Krylov basis V (row stride ldv), m and y from the
+// workspace lanczos_tridiag_kernel left: one streaming pass over the m basis vectors that were written.
+__global__ __launch_bounds__(256) void lanczos_combine_kernel(const double* __restrict__ V, int64_t ldv,
+                                                               const double* __restrict__ ws, const double* __restrict__ x0,
+                                                               double* __restrict__ x, int64_t D) {
+  const int m = (int)ws[0];
+  const double* y = ws + 1;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < D; k += (int64_t)gridDim.x * 256) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = 0;
+    for (; j + 1 < m; j += 2) {
+      acc0 += y[j] * V[(int64_t)j * ldv + k];
+      acc1 += y[j + 1] * V[(int64_t)(j + 1) * ldv + k];
+    }
+    if (j < m) acc0 += y[j] * V[(int64_t)j * ldv + k];
+    x[k] = x0[k] + (acc0 + acc1);
   }
 }
 
@@ -4162,7 +4238,6 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
 // is only a handle for hipGetSymbolAddress; the address kernels may use is looked up once per device,
 // with that device current, and kept.
 #define TTK_STATIC_SCRATCH_DOUBLES (4 * 1024 * 1024)   // 32 MiB
-#define TTK_MAX_DEVICES 64
 static __device__ __align__(256) double scratch[TTK_STATIC_SCRATCH_DOUBLES];
 static double* g_scratch_ptr[TTK_MAX_DEVICES];
 static std::mutex g_scratch_mutex;
@@ -4184,14 +4259,18 @@ static const int kTimingPool = 512;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
 static bool g_ev_created = false, g_ev_armed = false;
 static int g_ev_count = 0;
-static int g_ev_which = 1;   // 1: the Gram kernel, 2: the fused matrix-free product kernel
+static int g_ev_which = 1;   // which kernel is bracketed: see ttk_gram_timing
 
-static bool mvf_timing_begin(hipStream_t st) {
-  const bool timed = g_ev_armed && g_ev_which == 2 && g_ev_count < kTimingPool;
+// Shared with ttk_dense.hip: `which` names the kernel about to be launched on `st`.
+bool ttk_timing_begin(int which, hipStream_t st) {
+  const bool timed = g_ev_armed && g_ev_which == which && g_ev_count < kTimingPool;
   if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
   return timed;
 }
-static void mvf_timing_end(hipStream_t st) { (void)hipEventRecord(g_ev_stop[g_ev_count++], st); }
+void ttk_timing_end(hipStream_t st) { (void)hipEventRecord(g_ev_stop[g_ev_count++], st); }
+
+static bool mvf_timing_begin(hipStream_t st) { return ttk_timing_begin(2, st); }
+static void mvf_timing_end(hipStream_t st) { ttk_timing_end(st); }
 
 // =======================================================================================
 // C ABI
@@ -4206,7 +4285,7 @@ int ttk_gram_timing(int enable) {
     g_ev_created = true;
   }
   g_ev_armed = enable != 0;
-  g_ev_which = enable == 2 ? 2 : 1;
+  g_ev_which = enable >= 1 && enable <= 5 ? enable : 1;
   g_ev_count = 0;
   return TTK_OK;
 }
@@ -4663,7 +4742,12 @@ int ttk_rhs_f64(const double* L, const double* X, const double* R, const double*
   return rhs_run(L, X, R, g, b, S, C, rl, p, rr, accumulate, d, (double*)ws, (hipStream_t)stream);
 }
 
-int64_t ttk_rhs_static_max_bytes(void) { return (int64_t)TTK_STATIC_SCRATCH_DOUBLES * (int64_t)sizeof(double); }
+int64_t ttk_rhs_static_max_bytes(void) {
+  // Also the set-up call: the array's address on the current device is looked up here (when a device is
+  // there), so that a later ttk_rhs_static_f64 under stream capture finds it and touches no symbol table.
+  (void)static_scratch_ptr();
+  return (int64_t)TTK_STATIC_SCRATCH_DOUBLES * (int64_t)sizeof(double);
+}
 
 int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const double* g, double* b, int64_t S, int C,
                        int rl, int p, int rr, int accumulate, void* stream) {
@@ -4671,7 +4755,7 @@ int ttk_rhs_static_f64(const double* L, const double* X, const double* R, const 
   const RhsDims d = rhs_dims(S, C, rl, p, rr);
   if (d.CH < 4) return TTK_EINVAL;
   if (S * (int64_t)(rl > rr ? rl : rr) >= (1ll << 40)) return TTK_EINVAL;
-  if (ttk_rhs_ws_bytes(S, C, rl, p, rr) > ttk_rhs_static_max_bytes()) return TTK_EWORKSPACE;
+  if (ttk_rhs_ws_bytes(S, C, rl, p, rr) > (int64_t)TTK_STATIC_SCRATCH_DOUBLES * (int64_t)sizeof(double)) return TTK_EWORKSPACE;
   double* ws = static_scratch_ptr();
   if (!ws) return TTK_ELAUNCH;
   // every slab partial and every GL entry is written before it is read: nothing has to start at zero
@@ -4846,21 +4930,47 @@ int ttk_minres_update_f64(double* y, double* r1, double* r2, double* v, double* 
 }
 
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
-                           double* betas, int j, int64_t D, void* stream) {
-  if (!w || !v_cur || !v_next || !alphas || !betas || j < 1 || D < 1) return TTK_EINVAL;
+                           double* betas, int j, int64_t D, double tol, double* stop, void* stream) {
+  if (!w || !v_cur || !v_next || !alphas || !betas || !stop || j < 1 || D < 1) return TTK_EINVAL;
   if (D <= 8192)
     hipLaunchKernelGGL(lanczos_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
-                       alphas, betas, j, D);
+                       alphas, betas, j, D, tol, stop);
   else if (D < 2 * LZW_WG * 32) {
     hipLaunchKernelGGL(lanczos_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, v_prev, v_cur, v_next,
-                       alphas, betas, j, D);
+                       alphas, betas, j, D, tol, stop);
   } else {
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(lanczos_wide_kernel<0>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
-    hipLaunchKernelGGL(lanczos_wide_kernel<1>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
-    hipLaunchKernelGGL(lanczos_wide_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)v_next, alphas, betas, j);
-    hipLaunchKernelGGL(lanczos_wide_kernel<2>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D);
+    const double* cstop = stop;
+    hipLaunchKernelGGL(lanczos_wide_kernel<0>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D, cstop);
+    hipLaunchKernelGGL(lanczos_wide_kernel<1>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D, cstop);
+    hipLaunchKernelGGL(lanczos_wide_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)v_next, alphas, betas, j, tol,
+                       stop);
+    hipLaunchKernelGGL(lanczos_wide_kernel<2>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D, cstop);
   }
+  return ttk_launch_status();
+}
+
+int64_t ttk_lanczos_finish_ws_bytes(int m_cap) {
+  if (m_cap < 1) return TTK_EINVAL;
+  return (int64_t)(1 + 6 * (int64_t)m_cap) * (int64_t)sizeof(double);
+}
+
+int ttk_lanczos_finish_f64(const double* V, int64_t ldv, const double* alphas, const double* betas, const double* stop,
+                           int m_run, int m_cap, const double* x0, double* x, int64_t D, void* ws, int64_t ws_bytes,
+                           void* stream) {
+  if (!V || !alphas || !betas || !stop || !x0 || !x || !ws || D < 1 || ldv < D || m_run < 1 || m_cap < m_run)
+    return TTK_EINVAL;
+  if (ws_bytes < ttk_lanczos_finish_ws_bytes(m_cap)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)5 * m_cap * sizeof(double);
+  static bool allowed[TTK_MAX_DEVICES];
+  int in_lds = lds <= 64 * 1024;
+  if (!in_lds && lds <= 150 * 1024) in_lds = allow_big_lds((const void*)lanczos_tridiag_kernel, allowed, 150 * 1024) ? 1 : 0;
+  hipLaunchKernelGGL(lanczos_tridiag_kernel, dim3(1), dim3(64), in_lds ? lds : 0, st, alphas, betas, stop, m_run, m_cap,
+                     (double*)ws, in_lds);
+  int grid = (int)((D + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(lanczos_combine_kernel, dim3(grid), dim3(256), 0, st, V, ldv, (const double*)ws, x0, x, D);
   return ttk_launch_status();
 }
 

@@ -14,6 +14,10 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// HIP-event brackets around one kernel (ttk.hip; armed by ttk_gram_timing)
+bool ttk_timing_begin(int which, hipStream_t st);
+void ttk_timing_end(hipStream_t st);
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // Arithmetic of the matrix products of a kernel.  double: v_mfma_f64_16x16x4_f64.  float: v_mfma_f32_16x16x4_f32
@@ -908,20 +912,29 @@ static int conv_feature_rows(int px, int nab) {
   return (int)rb;
 }
 
-// dynamic LDS above 64 KiB (long K) has to be allowed once per kernel
+// Dynamic LDS above 64 KiB has to be allowed once per kernel AND per device (the attribute belongs to the
+// device's copy of the code object).  flags: one per device, owned by the call site.  Two threads that race
+// here both set the same attribute; nothing else is shared.
+#define DENSE_MAX_DEVICES 64
+static bool dense_allow_lds(const void* fn, bool* flags) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DENSE_MAX_DEVICES) return false;
+  if (flags[dev]) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) return false;
+  flags[dev] = true;
+  return true;
+}
+
 template <typename TC>
 static bool gemm_rows_allow_lds() {
-  static int state = 0;   // 0 not tried, 1 ok, -1 failed
-  if (state == 0) {
-    const void* fns[] = {(const void*)gemm_rows_kernel<0, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 0, 4, 1, TC>,
-                         (const void*)gemm_rows_kernel<2, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 1, 1, 6, TC>,
-                         (const void*)gemm_rows_kernel<1, 1, 2, 3, TC>, (const void*)gemm_rows_kernel<1, 1, 3, 2, TC>,
-                         (const void*)gemm_rows_kernel<1, 1, 4, 1, TC>};
-    state = 1;
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) state = -1;
-  }
-  return state == 1;
+  static bool flags[7][DENSE_MAX_DEVICES];
+  const void* fns[7] = {(const void*)gemm_rows_kernel<0, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 0, 4, 1, TC>,
+                        (const void*)gemm_rows_kernel<2, 0, 4, 1, TC>, (const void*)gemm_rows_kernel<1, 1, 1, 6, TC>,
+                        (const void*)gemm_rows_kernel<1, 1, 2, 3, TC>, (const void*)gemm_rows_kernel<1, 1, 3, 2, TC>,
+                        (const void*)gemm_rows_kernel<1, 1, 4, 1, TC>};
+  bool ok = true;
+  for (int k = 0; k < 7; ++k) ok = dense_allow_lds(fns[k], flags[k]) && ok;
+  return ok;
 }
 
 template <typename TC>
@@ -964,13 +977,11 @@ static int env_right_dense_launch(const double* R, const double* X, const double
     if (!d.lds && rr > 64) return TTK_EINVAL;   // bonds above 64 only on the resident route (see ttk_env_right_dense_ok)
     if (d.lds) {
       const dim3 rgrid((unsigned)(8 * d.ncb * d.nsplit));
+      const bool timed = ttk_timing_begin(4, st);
 #define ER_LAUNCH(TPL_, LB_, NA_)                                                                                        \
   {                                                                                                                      \
-    static bool allowed = false;   /* more than 64 KiB of dynamic LDS needs the attribute once per kernel */            \
-    if (!allowed && hipFuncSetAttribute((const void*)env_right_resident_kernel<TPL_, LB_, NA_, TC>,                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)           \
-      return TTK_ELAUNCH;                                                                                                \
-    allowed = true;                                                                                                      \
+    static bool allowed[DENSE_MAX_DEVICES];                                                                              \
+    if (!dense_allow_lds((const void*)env_right_resident_kernel<TPL_, LB_, NA_, TC>, allowed)) return TTK_ELAUNCH;       \
     hipLaunchKernelGGL((env_right_resident_kernel<TPL_, LB_, NA_, TC>), rgrid, dim3(512), d.lds, st, X, core, out, S, p, \
                        rl, rr, R, accumulate, d.ncb, d.rows_xcd, d.rows_wg);                                             \
   }
@@ -1007,6 +1018,7 @@ static int env_right_dense_launch(const double* R, const double* X, const double
       }
 #undef ER_LAUNCH_NA
 #undef ER_LAUNCH
+      if (timed) ttk_timing_end(st);
       return dense_status();
     }
   }
@@ -1041,13 +1053,11 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)d.ngroups, (unsigned)d.nslabs);
   double* partial = (double*)ws;
+  const bool timed = ttk_timing_begin(3, st);
 #define RF_LAUNCH(PTC_, NCW_)                                                                                          \
   {                                                                                                                    \
-    static bool allowed = false;   /* more than 64 KiB of dynamic LDS needs the attribute once per kernel */          \
-    if (!allowed && hipFuncSetAttribute((const void*)rhs_feature_kernel<PTC_, NCW_, TC>,                               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)         \
-      return TTK_ELAUNCH;                                                                                              \
-    allowed = true;                                                                                                    \
+    static bool allowed[DENSE_MAX_DEVICES];                                                                            \
+    if (!dense_allow_lds((const void*)rhs_feature_kernel<PTC_, NCW_, TC>, allowed)) return TTK_ELAUNCH;                \
     hipLaunchKernelGGL((rhs_feature_kernel<PTC_, NCW_, TC>), grid, dim3(512), d.lds, st, GL, X, R, partial, S, rl, p, \
                        rr, d.slab_len, d.gw);                                                                          \
   }
@@ -1060,6 +1070,7 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
   else
     RF_LAUNCH(16, 1)
 #undef RF_LAUNCH
+  if (timed) ttk_timing_end(st);
   int rc = dense_status();
   if (rc != TTK_OK) return rc;
   const int64_t D = (int64_t)rl * p * rr;

@@ -548,15 +548,30 @@ def minres_update(y, r1, r2, v, w, w2, x, state):
     _lib.check(rc, "ttk_minres_update_f64")
 
 
-def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
-    """Iteration j >= 1 of the Lanczos recurrence on w = A v_cur (in place); returns v_next.
-    alphas[j-1] and betas[j] are written on the device; v_prev may be None (first iteration)."""
-    v_next = torch.empty_like(w)
+def lanczos_update(w, v_prev, v_cur, v_next, alphas, betas, j, tol, stop):
+    """Iteration j >= 1 of the Lanczos recurrence on w = A v_cur (in place); v_next (a row of the basis) is written.
+    alphas[j-1] and betas[j] are written on the device; v_prev may be None (first iteration).  stop (1,) on the
+    device: set to j when betas[j] < tol, and once it is set every later call does nothing."""
     rc = _lib.lib().ttk_lanczos_update_f64(_chk(w, "w"), 0 if v_prev is None else _chk(v_prev, "v_prev"),
-                                           _chk(v_cur, "v_cur"), v_next.data_ptr(), _chk(alphas, "alphas"),
-                                           _chk(betas, "betas"), int(j), w.numel(), _stream(w))
+                                           _chk(v_cur, "v_cur"), _chk(v_next, "v_next"), _chk(alphas, "alphas"),
+                                           _chk(betas, "betas"), int(j), w.numel(), float(tol), _chk(stop, "stop"), _stream(w))
     _lib.check(rc, "ttk_lanczos_update_f64")
     return v_next
+
+
+def lanczos_finish(V, alphas, betas, stop, m_run, x0):
+    """x0 + V_m y with T_m y = beta_1 e_1 (m = stop[0] if set, else m_run): the tridiagonal solve in one workgroup
+    and one streaming pass over the rows of the basis V (m_cap + 1, D)."""
+    D = V.shape[1]
+    m_cap = V.shape[0] - 1
+    nbytes = int(_lib.lib().ttk_lanczos_finish_ws_bytes(m_cap))
+    ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=V.device)
+    x = torch.empty(D, dtype=F64, device=V.device)
+    rc = _lib.lib().ttk_lanczos_finish_f64(_chk(V, "V"), V.stride(0), _chk(alphas, "alphas"), _chk(betas, "betas"),
+                                           _chk(stop, "stop"), int(m_run), m_cap, _chk(x0, "x0"), x.data_ptr(), D, ws.data_ptr(),
+                                           nbytes, _stream(V))
+    _lib.check(rc, "ttk_lanczos_finish_f64")
+    return x
 
 
 def rows_dot(J, v):

@@ -143,3 +143,13 @@ class AutogradBregman(BregFunction):
         if only_loss:
             return loss
         return _autograd_grad_hess(loss, x)
+
+
+def closed_form_symmetric_hessian(loss_fn):
+    """True when `loss_fn` is one of the closed-form losses above evaluated by ttk_loss_f64 (their per-sample
+    Hessians are symmetric by construction: 2 * ones, diag(2), w^2 (diag(pi) - pi pi^T)); False for anything
+    differentiated by autograd or overridden by a caller, whose Hessian has to be looked at."""
+    for cls in (SquareBregFunction, XEAutogradBregman):
+        if isinstance(loss_fn, cls) and type(loss_fn).forward in (SquareBregFunction.forward, XEAutogradBregman.forward):
+            return True
+    return isinstance(loss_fn, AutogradLoss) and type(loss_fn).forward is AutogradLoss.forward and loss_fn._closed_form

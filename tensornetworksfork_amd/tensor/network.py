@@ -16,6 +16,7 @@ from collections import deque
 import torch
 
 from .. import ops
+from .bregman import closed_form_symmetric_hessian
 from .engine import ChainEngine
 from .node import TensorNode
 from .solvers import (_cholesky_solve, _host_solver, _scipy_kind, cg_solve, cg_solve_fused,  # noqa: F401
@@ -366,7 +367,8 @@ class TensorNetwork:
         total = self._host_scalar(self._batch_mean_loss(d, loss, batch_size)) if want_loss else None
         b = lp.rhs(g)
         front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None, "gen": None}
-        sym = self._hessian_symmetric(H, sharded=d.sharded)
+        # (the closed-form losses are symmetric by construction: no host read, no collective for them)
+        sym = closed_form_symmetric_hessian(loss_fn) or self._hessian_symmetric(H, sharded=d.sharded)
         if lp.compressed_gram(sym):
             # compressed symmetric Gram in the workspace, own Cholesky on it
             self._mark("front")
@@ -420,20 +422,28 @@ class TensorNetwork:
             m = 'exact'
         ridged = m == 'ridge_exact' or m.startswith('ridge_cholesky')
         ridge = 2 * eps_ if ridged else 0.0
+        lu = m in ('exact', 'ridge_exact')
         if front["ws"] is not None:
             ws = front["ws"]
             scale = ops.gram_scale(ws)
-            if m in ('exact', 'ridge_exact'):
+            self._mark("pre")
+            x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
+            self._mark("solve")
+            if not lu:
+                self._pend_pivot_check(info, node)
+            elif int(info.item()) != 0:
+                # the reference's LU with partial pivoting (torch.linalg.solve, tensor/network.py:304-310) also takes
+                # what is not positive definite; a matrix that is goes through the Cholesky kernels like the others
                 A_f = ops.gram_expand(ws, scale=scale, ridge=ridge, out=self._engine.dense_buffer(lp.D, b.device))
                 x = torch.linalg.solve(A_f, ops.solve_rhs(b, core if ridged else None, scale, ridge))
-            else:
-                self._mark("pre")
-                x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
-                self._mark("solve")
-                self._pend_pivot_check(info, node)
         else:
             A_f = front["A_f"]
-            if m in ('exact', 'ridge_exact'):
+            # scaling, ridge shift and the blocked Cholesky of the dense matrix, all on the device
+            x, info = ops.chol_solve_dense(A_f, b.reshape(-1).contiguous(),
+                                           core.reshape(-1).contiguous() if ridged else None, ridge)
+            if not lu:
+                self._pend_pivot_check(info, node)
+            elif int(info.item()) != 0:
                 scale = A_f.diagonal().abs().mean()
                 scale = torch.where(scale == 0, torch.ones_like(scale), scale)
                 A_f.div_(scale)
@@ -441,10 +451,6 @@ class TensorNetwork:
                     A_f.diagonal().add_(ridge)
                 rhs = ops.solve_rhs(b, core if ridged else None, scale, ridge).reshape(-1)
                 x = torch.linalg.solve(A_f, rhs)
-            else:   # scaling, ridge shift and the blocked Cholesky of the dense matrix, all on the device
-                x, info = ops.chol_solve_dense(A_f, b.reshape(-1).contiguous(),
-                                               core.reshape(-1).contiguous() if ridged else None, ridge)
-                self._pend_pivot_check(info, node)
         node.update_node(lp.back(x), lr=lr, adaptive_step=adaptive_step, min_norm=min_norm, max_norm=max_norm)
         return total
 
@@ -788,7 +794,7 @@ class TensorNetwork:
                 x0 = self._engine.to_canon(node, x0n.to(device)).reshape(lp.shape)
                 if d.sharded:
                     self._shard.broadcast_(x0)
-                step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol)
+                step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol, lockstep=d.sharded)
                 node.update_node(lp.back(step), lr=lr)
                 if block_callback is not None:
                     block_callback(NS, node)

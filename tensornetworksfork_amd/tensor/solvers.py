@@ -15,41 +15,53 @@ def _cholesky_solve(A_f, rhs):
     return torch.cholesky_solve(rhs.unsqueeze(-1), Lc).squeeze(-1)
 
 
-def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8):
+def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False):
     """Lanczos-Galerkin without re-orthogonalisation (tensor/network.py:796-824).
-    Each iteration is the operator product plus one fused vector kernel; alpha/beta
-    stay on the device; the beta < tol exit is tested every `check_every` iterations
-    and the basis truncated to the first hit, which gives the same result as leaving
-    the loop at that iteration."""
+    Each iteration is the operator product plus one fused vector kernel that writes the next row of the
+    basis; alpha / beta stay on the device.  The reference's exit (beta < tol) is taken inside that
+    kernel: it records the iteration and turns every later call into a no-op, which gives the same
+    result as leaving the loop there.  The host only looks at the record to stop queueing work: every
+    `check_every` iterations it starts a copy of it to pinned memory and reads the copy started one
+    period earlier, which has long arrived - no wait.  `lockstep` (sample-sharded runs: every rank
+    must queue the same number of products, each holds an all-reduce) reads the record itself at
+    those points instead.  The tridiagonal solve and x0 + V y run on the device (ops.lanczos_finish)."""
     shape = x0.shape
-    r0 = b - matvec(x0)
-    alphas = torch.zeros(max_iter, dtype=x0.dtype, device=x0.device)
-    betas = torch.zeros(max_iter + 1, dtype=x0.dtype, device=x0.device)
+    D = x0.numel()
+    dev = x0.device
+    x0 = x0.reshape(-1).contiguous()
+    r0 = b.reshape(-1) - matvec(x0.reshape(shape)).reshape(-1)
+    st = torch.zeros(2 * max_iter + 2, dtype=x0.dtype, device=dev)
+    alphas, betas, stop = st[:max_iter], st[max_iter:2 * max_iter + 1], st[2 * max_iter + 1:]
     beta1 = ops.dot(r0, r0).sqrt()
     betas[0] = beta1
-    V = [r0 / beta1]
+    if max_iter < 1:
+        return x0.reshape(shape)
+    V = torch.empty((max_iter + 1, D), dtype=x0.dtype, device=dev)     # row j = v_{j+1}
+    torch.div(r0, beta1, out=V[0])
     m = 0
+    in_flight = None
     for j in range(1, max_iter + 1):
-        w = matvec(V[j - 1])
+        w = matvec(V[j - 1].reshape(shape)).reshape(-1)
         if not w.is_contiguous():
             w = w.contiguous()
-        V.append(ops.lanczos_update(w, V[j - 2] if j > 1 else None, V[j - 1], alphas, betas, j))
+        ops.lanczos_update(w, V[j - 2] if j > 1 else None, V[j - 1], V[j], alphas, betas, j, tol, stop)
         m = j
-        if j % check_every == 0 or j == max_iter:
-            small = (betas[1:j + 1] < tol).nonzero()
-            if small.numel() > 0:
-                m = int(small[0].item()) + 1
-                break
-    a = alphas[:m]
-    Tm = torch.diag(a)
-    if m > 1:
-        off = betas[1:m]
-        Tm = Tm + torch.diag(off, diagonal=1) + torch.diag(off, diagonal=-1)
-    rhs = torch.zeros(m, dtype=x0.dtype, device=x0.device)
-    rhs[0] = beta1
-    yv = torch.linalg.solve(Tm, rhs)
-    Vm = torch.stack([v.reshape(-1) for v in V[:m]], dim=-1)
-    return x0 + (Vm @ yv).reshape(shape)
+        if j % check_every == 0 and j < max_iter:
+            if lockstep or not dev.type == 'cuda':
+                if stop.item() != 0.0:
+                    break
+            else:
+                if in_flight is not None:
+                    host, ready = in_flight
+                    ready.synchronize()
+                    if host.item() != 0.0:
+                        break
+                host = torch.empty(1, dtype=x0.dtype, pin_memory=True)
+                host.copy_(stop, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+                in_flight = (host, ready)
+    return ops.lanczos_finish(V, alphas, betas, stop, m, x0).reshape(shape)
 
 
 def cg_solve(matvec, b, x0, maxiter, rtol, check_every=10):

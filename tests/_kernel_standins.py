@@ -291,7 +291,9 @@ def minres_update(y, r1, r2, v, w, w2, x, st):
         st[k] = val
 
 
-def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
+def lanczos_update(w, v_prev, v_cur, v_next, alphas, betas, j, tol, stop):
+    if stop.item() != 0.0:
+        return v_next
     if v_prev is not None:
         w.sub_(betas[j - 1] * v_prev)
     a = (w * v_cur).sum()
@@ -299,11 +301,24 @@ def lanczos_update(w, v_prev, v_cur, alphas, betas, j):
     bj = (w * w).sum().sqrt()
     alphas[j - 1] = a
     betas[j] = bj
-    return w / bj
+    if bj.item() < tol:
+        stop[0] = float(j)
+    v_next.copy_(w / bj)
+    return v_next
+
+
+def lanczos_finish(V, alphas, betas, stop, m_run, x0):
+    m = int(stop.item()) if stop.item() != 0.0 else m_run
+    Tm = torch.diag(alphas[:m])
+    if m > 1:
+        Tm = Tm + torch.diag(betas[1:m], diagonal=1) + torch.diag(betas[1:m], diagonal=-1)
+    rhs = torch.zeros(m, dtype=F64)
+    rhs[0] = betas[0]
+    return x0 + V[:m].T @ torch.linalg.solve(Tm, rhs)
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature").split()
 
 
 def install(monkeypatch):

@@ -508,9 +508,12 @@ def test_krylov_vector_updates(D):
         w, vc = _rand((D,), 7), _rand((D,), 8)
         al, be = torch.zeros(5, dtype=torch.float64), torch.rand(6, dtype=torch.float64)
         w_ref, al_ref, be_ref = w.clone(), al.clone(), be.clone()
-        vn_ref = K.lanczos_update(w_ref, vp, vc, al_ref, be_ref, j)
+        vn_ref = K.lanczos_update(w_ref, vp, vc, torch.empty(D, dtype=torch.float64), al_ref, be_ref, j, 1e-30,
+                                  torch.zeros(1, dtype=torch.float64))
         w_dev, al_dev, be_dev = w.to(dev), al.to(dev), be.to(dev)
-        vn = ops.lanczos_update(w_dev, None if vp is None else vp.to(dev), vc.to(dev), al_dev, be_dev, j)
+        vn = ops.lanczos_update(w_dev, None if vp is None else vp.to(dev), vc.to(dev),
+                                torch.empty(D, dtype=torch.float64, device=dev), al_dev, be_dev, j, 1e-30,
+                                torch.zeros(1, dtype=torch.float64, device=dev))
         assert G.rel_err(vn, vn_ref) < 1e-12 and G.rel_err(w_dev, w_ref) < 1e-12
         assert G.rel_err(al_dev, al_ref) < 1e-12 and G.rel_err(be_dev, be_ref) < 1e-12
 
@@ -675,7 +678,10 @@ def test_lanczos_update_wide(D):
         outs = []
         for _ in range(2):
             w, al, be = w0.clone().to(dev), alphas.clone().to(dev), betas.clone().to(dev)
-            vn = ops.lanczos_update(w, None if prev is None else prev.to(dev), vc.to(dev), al, be, j)
+            stop = torch.zeros(1, dtype=torch.float64, device=dev)
+            vn = ops.lanczos_update(w, None if prev is None else prev.to(dev), vc.to(dev),
+                                    torch.empty(D, dtype=torch.float64, device=dev), al, be, j, 1e-30, stop)
+            assert stop.item() == 0.0
             outs.append((w.cpu(), vn.cpu(), al.cpu(), be.cpu()))
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b)
@@ -687,6 +693,50 @@ def test_lanczos_update_wide(D):
         assert abs(al[j - 1] - a_ref) <= 1e-12 * max(1.0, abs(a_ref))
         assert abs(be[j] - b_ref) <= 1e-12 * b_ref
         assert G.rel_err(w, wr) < 1e-12 and G.rel_err(vn, wr / b_ref) < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("D", [17, 5000, 9000, 40000])
+def test_lanczos_stop_and_finish(D):
+    """The exit of the reference's Lanczos loop (beta < tol, tensor/network.py:813) taken inside the vector kernel:
+    the iteration is recorded, later calls change nothing; and the end of the solver (tridiagonal solve by
+    elimination with partial pivoting + x0 + V y over the rows of the basis) against torch.linalg.solve on the dense
+    tridiagonal matrix and a matrix-vector product, with and without the exit, for tridiagonal matrices that force
+    row interchanges (small diagonal entries) and for sizes on both sides of the in-LDS limit."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    w0, vc = _rand((D,), 85), _rand((D,), 86)
+    vc = vc / vc.norm()
+    al, be = torch.zeros(4, dtype=torch.float64, device=dev), torch.zeros(5, dtype=torch.float64, device=dev)
+    stop = torch.zeros(1, dtype=torch.float64, device=dev)
+    w = w0.clone().to(dev)
+    vn = torch.zeros(D, dtype=torch.float64, device=dev)
+    ops.lanczos_update(w, None, vc.to(dev), vn, al, be, 2, 1e30, stop)        # beta < tol: iteration 2 is the last
+    assert stop.item() == 2.0
+    al2, be2, w2 = al.clone(), be.clone(), w.clone()
+    ops.lanczos_update(w, None, vc.to(dev), vn, al, be, 3, 1e30, stop)        # frozen
+    assert stop.item() == 2.0 and torch.equal(al, al2) and torch.equal(be, be2) and torch.equal(w, w2)
+    for m_cap, m_run, stop_at in ((1, 1, 0), (2, 2, 0), (7, 7, 0), (40, 33, 0), (40, 40, 12), (3000, 2500, 0),
+                                  (4200, 4100, 0)):
+        if m_cap * D > 3e7:
+            continue
+        g = torch.Generator().manual_seed(m_cap + D)
+        alphas = torch.rand(m_cap, generator=g, dtype=torch.float64) * 2 - 1
+        alphas[::3] *= 1e-3                                                    # small pivots: rows get interchanged
+        betas = torch.rand(m_cap + 1, generator=g, dtype=torch.float64) + 0.1
+        V = torch.rand(m_cap + 1, D, generator=g, dtype=torch.float64) - 0.5
+        x0 = torch.rand(D, generator=g, dtype=torch.float64)
+        m = stop_at if stop_at else m_run
+        Tm = torch.diag(alphas[:m]) + torch.diag(betas[1:m], 1) + torch.diag(betas[1:m], -1)
+        rhs = torch.zeros(m, dtype=torch.float64)
+        rhs[0] = betas[0]
+        yv = torch.linalg.solve(Tm, rhs)
+        ref = x0 + V[:m].T @ yv
+        V[m:] = float("nan")                                                   # rows beyond the basis are never read
+        got = ops.lanczos_finish(V.to(dev), alphas.to(dev), betas.to(dev),
+                                 torch.tensor([float(stop_at)], dtype=torch.float64, device=dev), m_run, x0.to(dev))
+        cond = torch.linalg.cond(Tm).item()
+        assert G.rel_err(got, ref) < 1e-13 * max(cond, 10.0), (m_cap, m_run, stop_at, cond)
 
 
 @gpu

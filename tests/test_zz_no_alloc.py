@@ -36,8 +36,12 @@ def test_rhs_static_matches_rhs_twice():
         torch.cuda.synchronize()
         assert torch.cuda.memory_allocated(dev) == before
         assert torch.equal(got, ref), (S, C, rl, p, rr)
-        # accumulating form on top of the previous result
+        # accumulating form on top of the previous result; the device's free memory as the driver reports it
+        # (which a hipMalloc inside the library would lower, unseen by torch's allocator) stays where it was
+        free_before = torch.cuda.mem_get_info(dev)[0]
         assert lib.ttk_rhs_static_f64(*args, got.data_ptr(), S, C, rl, p, rr, 1, st) == OK
+        torch.cuda.synchronize()
+        assert abs(torch.cuda.mem_get_info(dev)[0] - free_before) < (1 << 20)    # (the smallest device allocation is 2 MiB)
         assert lib.ttk_rhs_f64(*args, ref.data_ptr(), S, C, rl, p, rr, 1, ws.data_ptr(), nbytes, st) == OK
         torch.cuda.synchronize()
         assert torch.equal(got, ref)
