@@ -284,6 +284,20 @@ int ttk_rows_rhs_f64(const double* J, const double* g, double* b, int64_t S, int
  * tensor/network.py:788-789 for a site whose features were contracted first) in one kernel. */
 int ttk_lhl_f64(const double* L, const double* H, const double* z, double* GL, int64_t S, int C, int rl, void* stream);
 
+/* ---- front-ends: raw inputs -> per-site feature tensors ----
+ *
+ * ttk_feature_map_f64: the local feature maps of TNMLRegressor for all N sites in one launch
+ * (polynomial_basis / fbasis, models/tnml.py:11-23): X (S,N) -> out (N,S,p), out[i] the (S,p) tensor
+ * of site i.  kind 0: [x^0 .. x^(p-1)];  kind 1 (p = 2): [cos(pi x/2), sin(pi x/2)].
+ *
+ * ttk_patchify: k x k patches with the given stride of an image batch (S,Cin,H,W) as rows
+ * (S, patches+1, Cin*k*k+1) with a zero last row, a zero last column and a one in the corner:
+ * F.unfold(...).transpose(-2,-1) + the two torch.cat + the corner assignment of
+ * image_convolution_lanczos_MNIST.py:29-32 / CIFAR_lanczos_swipe.py:35-38.
+ * types: 0 float32 -> float32, 1 float64 -> float64, 2 float32 -> float64. */
+int ttk_feature_map_f64(const double* X, int64_t S, int N, int kind, int p, double* out, void* stream);
+int ttk_patchify(const void* img, int64_t S, int Cin, int H, int W, int k, int stride, int types, void* out, void* stream);
+
 /* ---- sites with many features (conv-featurised / operator columns) and explicit Jacobian rows ----
  *
  * ttk_conv_feature_{f64,f32}: G[ab, row] = sum_x X[row, x] F[x, ab] for rows = (sample, patch): the

@@ -59,6 +59,8 @@ SIGNATURES = {
     "ttk_minres_update_f64": (_int, [_c_dp] * 8 + [_i64, _c_dp]),
     "ttk_minres_update_ws_bytes": (_i64, [_i64]),
     "ttk_minres_update_ws_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _i64, _c_dp]),
+    "ttk_feature_map_f64": (_int, [_c_dp, _i64, _int, _int, _int, _c_dp, _c_dp]),
+    "ttk_patchify": (_int, [_c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp, _c_dp]),
     "ttk_conv_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_conv_feature_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_gemm_rows_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),

@@ -1079,7 +1079,92 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
   return dense_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// Front-ends that turn raw inputs into the per-site feature tensors the columns read.
+//
+// feature_map_kernel: the local feature maps of TNMLRegressor (models/tnml.py:11-23) for all N sites in one
+// launch: out[i][s][:] = [x^0 .. x^degree] (kind 0) or [cos(pi x / 2), sin(pi x / 2)] (kind 1) of x = X[s][i].
+// out is (N, S, p): site i's (S, p) tensor is one contiguous slice.  Powers 0..3 are 1, x, x*x, x*x*x (what
+// torch's x ** d evaluates for those exponents), higher ones pow(x, d).
+//
+// patchify_kernel: non-overlapping / strided k x k patches of an image batch (S, Cin, H, W) as rows
+// (S, patches + 1, Cin k k + 1) with a zero last row, a zero last column and a one in the corner:
+// torch.nn.functional.unfold(...).transpose(-2, -1) followed by the two torch.cat and the corner assignment of
+// image_convolution_lanczos_MNIST.py:29-32 (pixel index = c k k + ki k + kj, patch index = oh OW + ow).
+// Both are byte shuffles bound by HBM: consecutive lanes write consecutive output elements.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void feature_map_kernel(const double* __restrict__ X, int64_t S, int N, int kind, int p,
+                                                           double* __restrict__ out) {
+  const int64_t total = (int64_t)N * S * p;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int d = (int)(idx % p);
+    const int64_t is = idx / p;
+    const int64_t s = is % S;
+    const int i = (int)(is / S);
+    const double x = X[s * N + i];
+    double v;
+    if (kind == 0) {
+      v = d == 0 ? 1.0 : d == 1 ? x : d == 2 ? x * x : d == 3 ? x * x * x : pow(x, (double)d);
+    } else {
+      const double a = 1.5707963267948966 * x;
+      v = d == 0 ? cos(a) : sin(a);
+    }
+    out[idx] = v;
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ img, int64_t S, int Cin, int H, int W, int k,
+                                                        int stride, int OH, int OW, TO* __restrict__ out) {
+  const int px = Cin * k * k + 1, P = OH * OW + 1;
+  const int64_t total = S * P * px;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int x = (int)(idx % px);
+    const int64_t sp = idx / px;
+    const int pt = (int)(sp % P);
+    const int64_t s = sp / P;
+    TO v = (TO)0;
+    if (pt == P - 1 || x == px - 1) {
+      v = (pt == P - 1 && x == px - 1) ? (TO)1 : (TO)0;
+    } else {
+      const int c = x / (k * k), kk = x - c * k * k, ki = kk / k, kj = kk - ki * k;
+      const int oh = pt / OW, ow = pt - oh * OW;
+      v = (TO)img[((s * Cin + c) * H + (oh * stride + ki)) * W + (ow * stride + kj)];
+    }
+    out[idx] = v;
+  }
+}
+
 extern "C" {
+
+int ttk_feature_map_f64(const double* X, int64_t S, int N, int kind, int p, double* out, void* stream) {
+  if (!X || !out || S < 1 || N < 1 || kind < 0 || kind > 1 || p < 1 || (kind == 1 && p != 2)) return TTK_EINVAL;
+  const int64_t total = (int64_t)N * S * p;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(feature_map_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, S, N, kind, p, out);
+  return dense_status();
+}
+
+// in / out element types: 0 float32 -> float32, 1 float64 -> float64, 2 float32 -> float64
+int ttk_patchify(const void* img, int64_t S, int Cin, int H, int W, int k, int stride, int types, void* out, void* stream) {
+  if (!img || !out || S < 1 || Cin < 1 || k < 1 || stride < 1 || H < k || W < k || types < 0 || types > 2) return TTK_EINVAL;
+  const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
+  const int64_t total = S * (int64_t)(OH * OW + 1) * (int64_t)(Cin * k * k + 1);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipStream_t st = (hipStream_t)stream;
+  if (types == 0)
+    hipLaunchKernelGGL((patchify_kernel<float, float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)img, S, Cin, H, W, k,
+                       stride, OH, OW, (float*)out);
+  else if (types == 1)
+    hipLaunchKernelGGL((patchify_kernel<double, double>), dim3((unsigned)grid), dim3(256), 0, st, (const double*)img, S, Cin, H, W,
+                       k, stride, OH, OW, (double*)out);
+  else
+    hipLaunchKernelGGL((patchify_kernel<float, double>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)img, S, Cin, H, W, k,
+                       stride, OH, OW, (double*)out);
+  return dense_status();
+}
 
 int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream) {
   if (!X || !F || !G || rows < 1 || px < 1 || nab < 1) return TTK_EINVAL;

@@ -7,7 +7,9 @@ import torch
 from sklearn.base import BaseEstimator, RegressorMixin
 from sklearn.metrics import accuracy_score, r2_score
 
+from .. import ops
 from ..tensor.bregman import SquareBregFunction
+from ..tensor.engine import PAIR_CLASS_MAX_P
 from ..tensor.layers import TensorTrainLayer
 from ._common import (EarlyStopping, error_rate_torch, root_mean_squared_error_torch, split_train_val, to_tensor64,
                       unexplained_variance)
@@ -16,14 +18,36 @@ __all__ = ["TNMLRegressor", "EarlyStopping", "fbasis", "polynomial_basis", "root
            "error_rate_torch", "unexplained_variance"]
 
 
+def _on_device(X):
+    return isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float64 and X.ndim == 2 and X.shape[0] > 0
+
+
 def fbasis(X):
-    """[cos(pi x/2), sin(pi x/2)] per feature: list of (S, 2) (models/tnml.py:11-16)."""
+    """[cos(pi x/2), sin(pi x/2)] per feature: list of (S, 2) (models/tnml.py:11-16).  A float64 device
+    input goes through one kernel for all features (ttk_feature_map_f64)."""
+    if _on_device(X):
+        return list(ops.feature_map(X.contiguous(), "sincos", 2).unbind(0))
     h = 0.5 * math.pi
     return [torch.stack([torch.cos(h * X[:, i]), torch.sin(h * X[:, i])], dim=-1) for i in range(X.shape[-1])]
 
 
 def polynomial_basis(X, degree=3):
-    """[1, x, ..., x^degree] per feature: list of (S, degree+1) (models/tnml.py:18-23)."""
+    """[1, x, ..., x^degree] per feature: list of (S, degree+1) (models/tnml.py:18-23).  A float64 device
+    input goes through one kernel for all features; the products x^i x^j of such a basis depend on i + j
+    only, which the tensors carry along (`ttk_pair_rep`) so that the Gram kernel's feature-pair classes
+    need not be detected from the data."""
+    if _on_device(X):
+        p = degree + 1
+        feats = list(ops.feature_map(X.contiguous(), "poly", p).unbind(0))
+        if 2 <= p <= PAIR_CLASS_MAX_P:
+            first, rep = {}, []
+            for i in range(p):
+                for j in range(i, p):
+                    rep.append(first.setdefault(i + j, len(rep)))
+            for t in feats:
+                if rep != list(range(len(rep))):
+                    t.ttk_pair_rep = (rep, t._version)
+        return feats
     return [torch.stack([X[:, i] ** d for d in range(degree + 1)], dim=-1) for i in range(X.shape[-1])]
 
 

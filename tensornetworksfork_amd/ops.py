@@ -773,3 +773,38 @@ def chol_solve_dense(A, b, w=None, ridge=0.0):
     info = torch.empty((), dtype=torch.int32, device=A.device)
     _lib.check(_lib.lib().ttk_chol_solve_f64(cw.data_ptr(), D, x.data_ptr(), info.data_ptr(), st), "ttk_chol_solve_f64")
     return x, info
+
+
+def feature_map(X, kind, p):
+    """Per-site feature tensors of a raw input X (S, N) -> (N, S, p) (site i: out[i]); kind "poly": powers
+    0 .. p-1, "sincos" (p = 2): cos / sin of pi x / 2."""
+    S, N = X.shape
+    out = torch.empty((N, S, p), dtype=F64, device=X.device)
+    if S == 0:
+        return out
+    rc = _lib.lib().ttk_feature_map_f64(_chk(X, "X"), S, N, {"poly": 0, "sincos": 1}[kind], int(p), out.data_ptr(), _stream(X))
+    _lib.check(rc, "ttk_feature_map_f64")
+    return out
+
+
+def patchify(images, kernel_size, stride, dtype=None):
+    """(S, Cin, H, W) images -> (S, patches + 1, Cin k k + 1) patch rows with the zero row / column and the corner
+    one the image scripts append; float32 or float64 in, the same or float64 out."""
+    if not (isinstance(images, torch.Tensor) and images.is_cuda and images.is_contiguous() and images.ndim == 4
+            and images.dtype in (torch.float32, F64)):
+        raise _lib.TTKError("patchify: expected a contiguous float32 / float64 CUDA/HIP tensor (S, Cin, H, W)")
+    dtype = images.dtype if dtype is None else dtype
+    types = {(torch.float32, torch.float32): 0, (F64, F64): 1, (torch.float32, F64): 2}.get((images.dtype, dtype))
+    if types is None:
+        raise _lib.TTKError(f"patchify: {images.dtype} -> {dtype} is not supported")
+    S, Cin, H, W = images.shape
+    k, st = int(kernel_size), int(stride)
+    if H < k or W < k:
+        raise _lib.TTKError("patchify: kernel larger than the image")
+    OH, OW = (H - k) // st + 1, (W - k) // st + 1
+    out = torch.empty((S, OH * OW + 1, Cin * k * k + 1), dtype=dtype, device=images.device)
+    if S == 0:
+        return out
+    rc = _lib.lib().ttk_patchify(images.data_ptr(), S, Cin, H, W, k, st, types, out.data_ptr(), _stream(images))
+    _lib.check(rc, "ttk_patchify")
+    return out

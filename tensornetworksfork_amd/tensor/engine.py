@@ -802,6 +802,11 @@ class ChainEngine(EngineBase):
         if kind == "A":
             if not d.pairs_done:      # plain columns: G[0, 0] is the input itself
                 d.pairs_done = True
+                for j, c in enumerate(self.cols):
+                    # a feature map that knows its own classes (polynomial_basis) says so on the tensor
+                    hint = getattr(d.xs[j], "ttk_pair_rep", None) if c.kind == "plain" else None
+                    if hint is not None and hint[1] == d.xs[j]._version:
+                        self._pair_store(self.feats(d, j)[0, 0], "own", list(hint[0]))
                 self.prefetch_pairs([self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"])
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
             prob = LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)

@@ -810,3 +810,50 @@ def test_wide_krylov_updates_match_one_workgroup(D):
     assert float(outs_1[-1][1].item()) == 3.0          # three iterations were counted
     for a, b in zip(outs_w, outs_1):
         assert G.rel_err(a, b) < 1e-11
+
+
+@gpu
+@pytest.mark.parametrize("shape,k,st,dt_in,dt_out", [((300, 1, 28, 28), 4, 4, torch.float32, torch.float32),
+                                                     ((257, 3, 32, 32), 4, 4, torch.float32, torch.float32),
+                                                     ((64, 1, 28, 28), 4, 4, torch.float64, torch.float64),
+                                                     ((33, 2, 13, 17), 3, 2, torch.float32, torch.float64),
+                                                     ((5, 1, 4, 4), 4, 4, torch.float64, torch.float64)])
+def test_patchify_matches_unfold(shape, k, st, dt_in, dt_out):
+    """The patch rows of the image scripts (image_convolution_lanczos_MNIST.py:29-32): F.unfold + transpose + a zero
+    row + a zero column + corner one, bit for bit (a byte shuffle)."""
+    import torch.nn.functional as Fn
+    from tensornetworksfork_amd.tensor.features import patchify
+    dev = _dev()
+    img = torch.rand(*shape, generator=torch.Generator().manual_seed(3), dtype=dt_in)
+    x = Fn.unfold(img, kernel_size=(k, k), stride=(st, st), padding=0).transpose(-2, -1)
+    x = torch.cat((x, torch.zeros((x.shape[0], 1, x.shape[2]), dtype=dt_in)), dim=-2)
+    x = torch.cat((x, torch.zeros((x.shape[0], x.shape[1], 1), dtype=dt_in)), dim=-1)
+    x[..., -1, -1] = 1.0
+    got = patchify(img.to(dev), k, st, dtype=dt_out)
+    assert got.dtype == dt_out and tuple(got.shape) == tuple(x.shape)
+    assert torch.equal(got.cpu(), x.to(dt_out))
+
+
+@gpu
+def test_feature_maps_on_device():
+    """polynomial_basis / fbasis of a device input (one kernel for all sites) against the reference's formulas
+    (models/tnml.py:11-23) evaluated by torch on the CPU, and the feature-pair classes the polynomial basis
+    announces against the ones detected from the data."""
+    import math
+    from tensornetworksfork_amd.models.tnml import fbasis, polynomial_basis
+    from tensornetworksfork_amd.tensor.engine import pair_classes
+    dev = _dev()
+    X = torch.rand(1237, 7, generator=torch.Generator().manual_seed(4), dtype=torch.float64) * 2 - 1
+    for degree in (1, 3, 5, 7):
+        got = polynomial_basis(X.to(dev), degree)
+        ref = [torch.stack([X[:, i] ** d for d in range(degree + 1)], dim=-1) for i in range(X.shape[1])]
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert a.is_contiguous() and tuple(a.shape) == tuple(b.shape) and G.rel_err(a, b) < 1e-15
+        hint = getattr(got[2], "ttk_pair_rep", None)
+        assert (None if hint is None else hint[0]) == pair_classes(got[2])
+        assert hint is None or hint[1] == got[2]._version
+    got = fbasis(X.to(dev))
+    ref = [torch.stack([torch.cos(0.5 * math.pi * X[:, i]), torch.sin(0.5 * math.pi * X[:, i])], dim=-1) for i in range(7)]
+    for a, b in zip(got, ref):
+        assert G.rel_err(a, b) < 1e-15
