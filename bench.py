@@ -236,7 +236,7 @@ def _conv_identities(tn, x, y, bf):
         tn.forward(x)
         b = tn.get_b(node, g).to(f64)
         Av, Au = tn.matvec(node, v, H).to(f64), tn.matvec(node, u, H).to(f64)
-        quad = torch.einsum('sc,scd,sd->', Jv, H, Jv)
+        quad = (Jv.unsqueeze(2) * H * Jv.unsqueeze(1)).sum()      # sum_s (Jv)_s^T H_s (Jv)_s
         res = {"linearity": ((f1 - f0) - Jv).norm() / Jv.norm(),
                "adjoint": abs((b * v.to(f64)).sum() - (g * Jv).sum()) / (g.norm() * Jv.norm()),
                "symmetry": abs((u.to(f64) * Av).sum() - (v.to(f64) * Au).sum()) / (Av.norm() * u.to(f64).norm()),
