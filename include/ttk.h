@@ -193,7 +193,9 @@ int ttk_chol_solve_gram_f64(const void* gram_ws, int rl, int p, int rr, int sym_
  * Returns the previous mode; any other argument only queries.  Two ranges tune the single launch:
  * 100 + u keeps u compute units for its diagonal chain (100: chosen from the order), 1000 + k lets a
  * waiting lane give up after k polls (1000: the default of two million), which aborts the launch with
- * info = -1 and is how the tests check that every wait ends. */
+ * info = -1 and is how the tests check that every wait ends.  200 / 201: the backward substitution behind
+ * the single-launch factorisation as one launch per group of four block rows / as one launch of workgroups
+ * that wait for each other's block rows (201, the default; same operations, same bits). */
 int ttk_chol_mode(int mode);
 
 /* Reduced Householder QR of a row-major (m,n) matrix in one workgroup, LAPACK sign

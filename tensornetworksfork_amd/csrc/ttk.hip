@@ -3929,6 +3929,137 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
   }
 }
 
+// Backward substitution x = L^-T y as ONE launch behind the single-launch factorisation: the group solves and
+// block updates of chol_back_kernel (same operations in the same order, hence the same bits), with the kernel
+// boundaries between groups replaced by progress words.  Workgroup `blockIdx.x` owns block row k = nb-1-blockIdx.x,
+// i.e. workgroups are dispatched in the order in which they can finish: a workgroup only ever waits for rows of
+// higher index.  It walks the groups of BKG rows from the top down to its own; for a group above its own it
+// removes the group from its y_k (kept in LDS), and when every group above has been removed it publishes y_k
+// (write-through stores, vmcnt(0), barrier, progress word = BACK_READY in the row's slot of the factorisation's
+// control block, whose counts stay far below that value).  The matrices of a group (which depend on the
+// factorisation only) are fetched before the wait for its rows.  Every spin is bounded and ends through the
+// abort word like the factorisation's.
+#define BACK_READY 0x40000000u
+__device__ __forceinline__ double back_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void back_store(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void chol_back_chain_kernel(double* __restrict__ aug, int ld, int nb,
+                                                              const double* __restrict__ invL_all, double* __restrict__ x,
+                                                              int n, unsigned* __restrict__ ctl, int* __restrict__ info) {
+  __shared__ double part[BKG][4][CHB];
+  __shared__ double xs[BKG][CHB];
+  __shared__ double ys[BKG][CHB];
+  __shared__ double yk[CHB];
+  __shared__ unsigned seen;
+  unsigned* rowready = ctl + DAG_SLOT;
+  const unsigned spin_limit = ctl[4];
+  double* y = aug + ((int64_t)nb * CHB) * ld;
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int k = nb - 1 - (int)blockIdx.x;
+  const int tk = (nb - 1 - k) / BKG;
+  if (threadIdx.x < CHB) yk[c] = y[k * CHB + c];
+  if (tk == 0 && threadIdx.x == 0) dag_post(rowready + (size_t)k * DAG_SLOT, BACK_READY);   // nothing above it
+  for (int t = 0; t <= tk; ++t) {
+    const int jhi = nb - 1 - BKG * t;
+    const int jlo = jhi - BKG + 1 > 0 ? jhi - BKG + 1 : 0;
+    const int ng = jhi - jlo + 1;
+    const bool tail = t < tk;
+    double iv[BKG][16], lg[BKG][BKG - 1][16], gl[BKG][16];
+#pragma unroll
+    for (int m = 0; m < BKG; ++m) {
+      const int mm = m < ng ? m : ng - 1;   // clamped, never used when m >= ng
+      const double* invL = invL_all + (int64_t)(jlo + mm) * CHB * CHB;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) iv[m][e] = invL[(g * 16 + e) * CHB + c];
+#pragma unroll
+      for (int u = 0; u < BKG - 1; ++u) {   // rows of block jlo+m against columns of block jlo+u (u < m)
+        const int uu = u < mm ? u : 0;
+        const double* Lmt = aug + ((int64_t)(jlo + mm) * CHB + g * 16) * ld + (int64_t)(jlo + uu) * CHB + c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lg[m][u][e] = Lmt[(int64_t)e * ld];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < BKG; ++m) {
+      const int mm = m < ng ? m : ng - 1;
+      const double* Lmk = aug + ((int64_t)(jlo + mm) * CHB + g * 16) * ld + (int64_t)(tail ? k : 0) * CHB + c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gl[m][e] = Lmk[(int64_t)e * ld];
+    }
+    if (threadIdx.x == 0) {   // the rows of the group are final
+      unsigned ok = 1, spins = 0;
+      for (;;) {
+        unsigned a = BACK_READY;
+        for (int m = 0; m < ng; ++m) a = min(a, dag_poll(rowready + (size_t)(jlo + m) * DAG_SLOT));
+        if (a >= BACK_READY) break;
+        if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {
+          dag_post(ctl + 1, 1u);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      seen = ok;
+    }
+    __syncthreads();
+    if (!seen) {
+      if (threadIdx.x == 0) atomicCAS(info, 0, -1);
+      return;
+    }
+    if (g < ng) ys[g][c] = (jlo + g == k) ? yk[c] : back_load(y + (jlo + g) * CHB + c);
+    __syncthreads();
+#pragma unroll
+    for (int m = BKG - 1; m >= 0; --m) {
+      if (m < ng) {   // uniform
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += (g * 16 + e >= c ? iv[m][e] : 0.0) * ys[m][g * 16 + e];
+        part[0][g][c] = acc;
+        __syncthreads();
+        if (g == 0) {
+          const double v = part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c];
+          xs[m][c] = v;
+          if (!tail && k == jlo && (jlo + m) * CHB + c < n) x[(jlo + m) * CHB + c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BKG - 1; ++u)
+          if (u < m) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc += lg[m][u][e] * xs[m][g * 16 + e];
+            part[u][g][c] = sacc;
+          }
+        __syncthreads();
+        if (g < m) ys[g][c] -= part[g][0][c] + part[g][1][c] + part[g][2][c] + part[g][3][c];
+        __syncthreads();
+      }
+    }
+    if (tail) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = 0; m < BKG; ++m)
+        if (m < ng) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sacc += gl[m][e] * xs[m][g * 16 + e];
+        }
+      part[0][g][c] = sacc;
+      __syncthreads();
+      if (g == 0) yk[c] -= part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c];
+      __syncthreads();
+      if (t == tk - 1) {   // every group above has been removed: y_k is final
+        if (g == 0) back_store(y + k * CHB + c, yk[c]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) dag_post(rowready + (size_t)k * DAG_SLOT, BACK_READY);
+      }
+    }
+  }
+}
+
 // Gram expansion straight into the Cholesky storage: lower triangle of A/scale + ridge*I,
 // identity on the padded diagonal, zero elsewhere in the padded rows.
 __global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __restrict__ G, int rl, int p, int rr,
@@ -4536,7 +4667,12 @@ int ttk_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SY
 static int g_chol_mode = -1;
 static int g_dag_chain = 0;   // compute units kept for the diagonal chain; 0: chosen from the order
 static int g_dag_spin_limit = DAG_SPIN_LIMIT;
+static int g_back_chain = 1;  // the backward substitution behind the single-launch factorisation as one launch
 int ttk_chol_mode(int mode) {
+  if (mode == 200 || mode == 201) {   // testing: 200 one launch per group of block rows, 201 one launch in all
+    g_back_chain = mode - 200;
+    return g_chol_mode;
+  }
   if (mode >= 1000) {   // testing: polls before a waiting lane gives up (1000 restores the default)
     g_dag_spin_limit = mode > 1000 ? mode - 1000 : (int)DAG_SPIN_LIMIT;
     return g_chol_mode;
@@ -4614,7 +4750,14 @@ static int chol_solve_impl(void* chol_ws, int n, double* x, int* info, hipStream
                          invL, info, ctl, nchain, DagGram{});
     int rc = ttk_launch_status();
     if (rc != TTK_OK) return rc;
-    return chol_back_substitute(st, aug, ld, nb, invL, x, n);   // invL already holds the inverses
+    // invL already holds the inverses.  One launch for the whole substitution while every workgroup of it fits the
+    // device at once (they wait for each other); the one-launch-per-group form beyond (ttk_chol_mode(200) forces it)
+    if (g_back_chain && nb <= slots) {
+      hipLaunchKernelGGL(chol_back_chain_kernel, dim3((unsigned)nb), dim3(256), 0, st, aug, ld, nb, (const double*)invL, x, n, ctl,
+                         info);
+      return ttk_launch_status();
+    }
+    return chol_back_substitute(st, aug, ld, nb, invL, x, n);
   }
   if (gs)
     hipLaunchKernelGGL(gram_expand_lower_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)ld), dim3(256), 0, st, gs->G,

@@ -820,9 +820,13 @@ class ChainEngine(EngineBase):
         ca, cb = col.ca, col.cb
         A2 = core.reshape(col.rl * col.p, col.rr)
 
+        U_of = {}
+
         def M(a, b):
-            U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
-            return ops.lcontract(L[a], U)                  # (S, C, p)
+            if b not in U_of:      # U_b = A . R_b is shared by the left environments L_a of a convolution bond
+                U_of.clear()       # (callers walk b in the outer loop: one U alive at a time)
+                U_of[b] = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
+            return ops.lcontract(L[a], U_of[b])            # (S, C, p)
 
         if col.kind == "op" and ca == 1 and cb == 1:
             u, dd = col.inner

@@ -396,6 +396,35 @@ def test_cholesky_single_launch_matches_multi_launch(n):
 
 
 @gpu
+@pytest.mark.parametrize("n", [40, 200, 257, 1000, 2304, 6144])
+def test_backward_substitution_one_launch_equals_one_launch_per_group(n):
+    """Behind the single-launch factorisation the backward substitution runs as one launch of workgroups that wait
+    for each other's block rows; against one launch per group of block rows: the same bits (same operations in the
+    same order), for group counts that do and do not divide the block rows, repeatably."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(90 + n)
+    M = torch.randn(n, n + 32, generator=g, dtype=torch.float64, device=dev)
+    A = M @ M.T / (n + 32) + 0.05 * torch.eye(n, dtype=torch.float64, device=dev)
+    b = torch.randn(n, generator=g, dtype=torch.float64, device=dev)
+    old = ops.chol_mode(1)
+    try:
+        ops.chol_mode(200)
+        x0, i0 = ops.chol_solve_dense(A, b)
+        ops.chol_mode(201)
+        x1, i1 = ops.chol_solve_dense(A, b)
+        assert int(i0.item()) == int(i1.item()) == 0
+        assert torch.equal(x0, x1), n
+        for _ in range(3):
+            assert torch.equal(ops.chol_solve_dense(A, b)[0], x1)
+        scale = A.diagonal().abs().mean()
+        assert (((A / scale) @ x1 + b / scale).norm() / (b / scale).norm()).item() < 1e-10
+    finally:
+        ops.chol_mode(201)
+        ops.chol_mode(old)
+
+
+@gpu
 def test_cholesky_single_launch_gives_up_cleanly():
     """Every wait inside the single-launch factorisation is bounded: with the patience of a waiting lane cut to
     a handful of polls the launch aborts itself (info = -1) instead of hanging, and the next solve is fine."""
