@@ -4099,6 +4099,52 @@ __global__ __launch_bounds__(256) void gram_expand_lower_kernel(const double* __
 // register arithmetic plus one wave reduction; a reflector crosses waves through a double-buffered
 // LDS vector (one barrier per column) and is kept in LDS for the Q formation, which needs no
 // barrier at all (columns are independent).  Same arithmetic and sign convention as qr_kernel.
+// Sums of eight per-lane values over the 64 lanes of a wave, every total on every lane.  A butterfly in which
+// the lanes first split the eight sums among themselves (offsets 32, 16, 8: a lane passes on the half it gives
+// up, 4 + 2 + 1 exchanges), then finish their own one (offsets 1, 2, 4 within a row of 16 lanes), then read all eight back from the lanes
+// that hold them (scalar lane reads): 10 exchanges + 8 lane reads instead of 8 x 6 exchanges; fixed order.
+__device__ __forceinline__ double qr_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// v of another lane of the same row of 16 by a data-parallel-primitive move (no trip through the LDS crossbar):
+// 0xB1 / 0x4E = lanes xor 1 / xor 2 (quad permutations), 0x141 / 0x140 = mirror within 8 / 16 lanes, 0x128 = rotation by 8.
+template <int CTRL>
+__device__ __forceinline__ double qr_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, the same value (and bits) on every lane
+__device__ __forceinline__ double qr_wave_sum(double v) {
+  v += qr_dpp<0xB1>(v);
+  v += qr_dpp<0x4E>(v);
+  v += qr_dpp<0x141>(v);
+  v += qr_dpp<0x140>(v);
+  return (qr_readlane(v, 0) + qr_readlane(v, 16)) + (qr_readlane(v, 32) + qr_readlane(v, 48));
+}
+__device__ __forceinline__ void qr_wave_sum8(double (&acc)[8], int lane) {
+  double a4[4], a2[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double give = h5 ? acc[q] : acc[q + 4], keep = h5 ? acc[q + 4] : acc[q];
+    a4[q] = keep + __shfl_xor(give, 32, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double give = h4 ? a4[q] : a4[q + 2], keep = h4 ? a4[q + 2] : a4[q];
+    a2[q] = keep + __shfl_xor(give, 16, 64);
+  }
+  double one = (h3 ? a2[1] : a2[0]) + qr_dpp<0x128>(h3 ? a2[0] : a2[1]);   // row rotation by 8 = lane xor 8
+  one += qr_dpp<0xB1>(one);
+  one += qr_dpp<0x4E>(one);
+  one += qr_dpp<0x141>(one);
+  // sum q = 4 b5 + 2 b4 + b3 sits in the lanes with those bits: read it from the first of them
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = qr_readlane(one, ((q >> 2) & 1) * 32 + ((q >> 1) & 1) * 16 + (q & 1) * 8);
+}
+
 #define QRS_RPL 4
 #define QRS_CPW 8
 __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict__ Ain, int m, int n,
@@ -4133,12 +4179,8 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
         if (r > j) part += col[e] * col[e];
         if (r == j) mine = col[e];
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        part += __shfl_xor(part, off, 64);
-        mine += __shfl_xor(mine, off, 64);   // only the lane that holds row j contributes
-      }
-      const double alpha = mine;
+      part = qr_wave_sum(part);
+      const double alpha = qr_readlane(mine, j & 63);   // the lane that holds row j
       double t = 0.0, beta = alpha, scale = 0.0;
       if (part != 0.0) {
         const double nrm = sqrt(alpha * alpha + part);
@@ -4174,11 +4216,7 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
       for (int e = 0; e < QRS_RPL; ++e) d += v[e] * a[q][e];
       acc[q] = d;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int q = 0; q < QRS_CPW; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
-    }
+    qr_wave_sum8(acc, lane);
 #pragma unroll
     for (int q = 0; q < QRS_CPW; ++q) {
       const int c = wave + 4 * q;
@@ -4216,11 +4254,7 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
       for (int e = 0; e < QRS_RPL; ++e) d += v[e] * a[q][e];
       acc[q] = d;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int q = 0; q < QRS_CPW; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
-    }
+    qr_wave_sum8(acc, lane);
 #pragma unroll
     for (int q = 0; q < QRS_CPW; ++q) {
       const int c = wave + 4 * q;
