@@ -763,6 +763,30 @@ class ChainEngine(EngineBase):
         self.right(d, k)
         self.feats(d, k)
 
+    def output_at(self, d, node, lp, core=None, rows=None):
+        """The prediction a node's update starts from.  A sweep that arrives at column k from the left still holds
+        the right environment that includes column k (built on the way back of the sweep before, or with the
+        first environments), one that arrives from the right the left environment that includes it: the prediction
+        is then one row-dot kernel over the two cached environments instead of an environment step through the
+        node followed by it.  Anything else (a trial core, a sample range, no cached neighbour) goes through the
+        local problem."""
+        if core is None and rows is None:
+            self.sync(d)
+            k, _ = self.column_of(node)
+            N = len(self.cols)
+            if k >= 1 and d.R[k - 1] is not None and d.L[k] is not None:
+                Lk, Rk = d.L[k], d.R[k - 1]
+            elif k + 1 < N and d.L[k + 1] is not None and d.R[k] is not None:
+                Lk, Rk = d.L[k + 1], d.R[k]
+            else:
+                Lk = None
+            if Lk is not None and Lk.shape[0] == Rk.shape[0]:
+                y = ops.predict(Lk[0], Rk[0])
+                for a in range(1, Lk.shape[0]):
+                    ops.predict(Lk[a], Rk[a], out=y)
+                return y
+        return super().output_at(d, node, lp, core, rows)
+
     def refresh(self, d):
         """Bring every cached environment up to date (the reference's recompute_all_stacks)."""
         self.sync(d)
