@@ -3711,19 +3711,45 @@ struct DagGram {
 // x / d for 0 <= x < 2^21 with inv = 1.0f / d: (x + 0.5) * inv is at least 0.5 / d away from every integer, the
 // rounding error of the product stays below x * 2^-22 < 0.5 / d.
 __device__ __forceinline__ int dag_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// The 16 entries (row, col0 + 16 u + 4 t + kq) of A that one lane's accumulators of a tile start from.  The row's
+// indices are split once, the 16 loads are unconditional (indices clamped to the matrix) and in flight together;
+// scale, ridge and the identity padding are applied afterwards.  `sc` = scale[0], read once per kernel.
 template <bool LAZY>
-__device__ __forceinline__ double dag_a(const double* __restrict__ aug, int ld, const DagGram& gs, int row, int col) {
-  if (!LAZY || row >= ld) return aug[(int64_t)row * ld + col];
-  if (row >= gs.D) return row == col ? 1.0 : 0.0;
-  const int lp = dag_div(row, gs.inv_rr), r = row - lp * gs.rr, l = dag_div(lp, gs.inv_p), pp = lp - l * gs.p;
-  const int mq = dag_div(col, gs.inv_rr), t = col - mq * gs.rr, m = dag_div(mq, gs.inv_p), q = mq - m * gs.p;
-  const int a = gs.sym ? tri_index(min(l, m), max(l, m), gs.rl) : l * gs.rl + m;
-  const int b = tri_index(min(pp, q), max(pp, q), gs.p);
-  const int c = tri_index(min(r, t), max(r, t), gs.rr);
-  double v = gs.G[((int64_t)a * gs.NX + b) * gs.NRpad + c];
-  if (gs.scale) v = v / gs.scale[0];
-  if (row == col) v += gs.ridge;
-  return v;
+__device__ __forceinline__ void dag_a_tile(d4 (&out)[4], const double* __restrict__ aug, int ld, const DagGram& gs,
+                                           double sc, int row, int col0, int kq) {
+  if (!LAZY || row >= ld) {   // (uniform over the tile: only the right-hand-side block row lies beyond ld)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[u][t] = aug[(int64_t)row * ld + col0 + 16 * u + 4 * t + kq];
+    return;
+  }
+  const int rowc = min(row, gs.D - 1);
+  const int lp = dag_div(rowc, gs.inv_rr), r = rowc - lp * gs.rr, l = dag_div(lp, gs.inv_p), pp = lp - l * gs.p;
+  double g[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int colc = min(col0 + 16 * u + 4 * t + kq, gs.D - 1);
+      const int mq = dag_div(colc, gs.inv_rr), tt = colc - mq * gs.rr, m = dag_div(mq, gs.inv_p), q = mq - m * gs.p;
+      const int a = gs.sym ? tri_index(min(l, m), max(l, m), gs.rl) : l * gs.rl + m;
+      const int b = tri_index(min(pp, q), max(pp, q), gs.p);
+      const int c = tri_index(min(r, tt), max(r, tt), gs.rr);
+      g[u][t] = gs.G[((int64_t)a * gs.NX + b) * gs.NRpad + c];
+    }
+  const bool scaled = gs.scale != nullptr;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = col0 + 16 * u + 4 * t + kq;
+      double v = g[u][t];
+      if (scaled) v = v / sc;
+      if (row == col) v += gs.ridge;
+      if (row >= gs.D || col >= gs.D) v = row == col ? 1.0 : 0.0;   // identity beyond order D
+      out[u][t] = v;
+    }
 }
 
 template <bool LAZY>
@@ -3735,6 +3761,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc((void*)Winv, 0, nb * CHB * CHB * (int)sizeof(double), 0x00020000);
   unsigned* rowready = ctl + DAG_SLOT;
+  const double sc = (LAZY && gs.scale) ? gs.scale[0] : 1.0;
   // worker tasks: column j has rows j+2 .. nb in pairs, (nb - j) / 2 tasks
   int ntasks = 0;
   for (int jj = 0; jj < nb; ++jj) ntasks += (nb - jj) / 2;
@@ -3788,13 +3815,8 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
       const bool two = i + 1 <= nb;
       const int i2 = two ? i + 1 : i;   // a lone last row is simply done twice
       d4 acc[2][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          acc[0][u][t] = dag_a<LAZY>(aug, ld, gs, i * CHB + r_own, j * CHB + 16 * u + 4 * t + kq);
-          acc[1][u][t] = dag_a<LAZY>(aug, ld, gs, i2 * CHB + r_own, j * CHB + 16 * u + 4 * t + kq);
-        }
+      dag_a_tile<LAZY>(acc[0], aug, ld, gs, sc, i * CHB + r_own, j * CHB, kq);
+      dag_a_tile<LAZY>(acc[1], aug, ld, gs, sc, i2 * CHB + r_own, j * CHB, kq);
       const int qrow[2] = {i, i2};
       if (!dag_accumulate<2>(acc, rs, ld, j, qrow, 0, j, rowready, ctl, tid) ||
           !dag_wait(rowready, ctl, j, j, j, (unsigned)j + 1u, tid)) {   // ... and W_j
@@ -3834,15 +3856,13 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(double* __restrict__ a
     const int j = task;
     DAG_TRACE(j, 0)
     d4 acc[2][4];
+    dag_a_tile<LAZY>(acc[0], aug, ld, gs, sc, j * CHB + r_own, j * CHB, kq);
+    dag_a_tile<LAZY>(acc[1], aug, ld, gs, sc, (j + 1) * CHB + r_own, j * CHB, kq);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int c = 16 * u + 4 * t + kq;
-        const double v = dag_a<LAZY>(aug, ld, gs, j * CHB + r_own, j * CHB + c);
-        acc[0][u][t] = c <= r_own ? v : 0.0;   // only the lower triangle of A_jj is used
-        acc[1][u][t] = dag_a<LAZY>(aug, ld, gs, (j + 1) * CHB + r_own, j * CHB + c);
-      }
+      for (int t = 0; t < 4; ++t)
+        if (16 * u + 4 * t + kq > r_own) acc[0][u][t] = 0.0;   // only the lower triangle of A_jj is used
     {
       // Both tiles up to block column j-2; then the diagonal tile's last term, L_{j,j-1}, which is what the
       // chain waits for.  The second tile's last term, L_{j+1,j-1}, comes from a worker and is taken in behind
