@@ -4741,19 +4741,22 @@ int ttk_chol_mode(int mode) {
 }
 
 // workgroups of the single-launch factorisation that fit the device at once (more would only queue)
-static int chol_dag_slots() {
+static int chol_dag_slots(bool lazy) {
   static std::mutex mu;
-  static int slots[64];
+  static int slots[2][TTK_MAX_DEVICES];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TTK_MAX_DEVICES) return 256;
   std::lock_guard<std::mutex> lock(mu);
-  if (slots[dev] == 0) {
+  int& sl = slots[lazy ? 1 : 0][dev];
+  if (sl == 0) {   // occupancy of the instantiation that is launched
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const hipError_t e = lazy ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel<true>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_dag_kernel<false>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    slots[dev] = per_cu * cus;
+    sl = per_cu * cus;
   }
-  return slots[dev];
+  return sl;
 }
 
 static int chol_back_substitute(hipStream_t st, double* aug, int ld, int nb, const double* invL, double* x, int n) {
@@ -4793,7 +4796,7 @@ static int chol_solve_impl(void* chol_ws, int n, double* x, int* info, hipStream
       if (hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), g_dag_spin_limit, 1, st) != hipSuccess) return TTK_ELAUNCH;
     }
     // every slot of the device gets a workgroup, so that each compute unit sees its first arrival at once
-    const int slots = chol_dag_slots();
+    const int slots = chol_dag_slots(gs != nullptr);
     int nchain = g_dag_chain > 0 ? g_dag_chain : max(2, min(24, nb / 4));
     nchain = max(1, min(nchain, slots / 16));   // most of the device must stay with the workers
     if (gs)

@@ -25,6 +25,10 @@ from .solvers import (_cholesky_solve, _host_solver, _scipy_kind, cg_solve, cg_s
 _LEGACY_KWARGS = ("eps_r", "delta", "D_reg_fn")  # accepted and ignored: stale call sites pass them
 
 
+class _FactorisationAborted(Exception):
+    """The single-launch Cholesky gave up waiting (info = -1); the node update has been undone."""
+
+
 class TensorNetwork:
     def __init__(self, input_nodes, main_nodes, train_nodes=None, output_labels=('s',), sample_dim='s'):
         self.input_nodes = input_nodes
@@ -503,8 +507,7 @@ class TensorNetwork:
             for n, t, labels, left, right in snapshot:
                 n.tensor, n.dim_labels, n.left_labels, n.right_labels = t, labels, left, right
             if bad < 0:
-                raise RuntimeError("ttk_chol_solve_f64: the single-launch factorisation was aborted (a workgroup waited "
-                                   "for a tile beyond its limit); the update has been undone")
+                raise _FactorisationAborted()
             raise torch.linalg.LinAlgError(
                 "linalg.cholesky: The factorization could not be completed because the input is not "
                 f"positive-definite (the leading minor of order {bad} is not positive-definite).")
@@ -587,24 +590,36 @@ class TensorNetwork:
                     print(f"Timeout reached ({timeout} seconds). Stopping accumulating_swipe.")
                     return False
                 try:
-                    if method == 'gradient':
-                        loss = self._gradient_pass(d, node, y, loss_fn, batch_size, lr, adaptive_step, min_norm, max_norm,
-                                                   per_batch_update=(which == "fwd"))
-                    else:
-                        loss = self._site_update(d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step,
-                                                 min_norm, max_norm, want_loss)
-                    if orthonormalize:
-                        (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
-                    if self._streams is not None:   # what the callbacks of this update may look at is queued
-                        self._nodes_ready = torch.cuda.Event()
-                        self._nodes_ready.record()
-                    if i + 1 < len(order) and method != 'gradient':
-                        # the next node's Gram matrix is queued before the host waits for the pivot flag
-                        # and before the callbacks take the host (see _speculate)
-                        nxt = order[i + 1]
-                        if not (nxt in self.node_indices and self.node_indices[nxt] == self.node_indices.get(last[other])):
-                            self._speculate(d, nxt, y, loss_fn, batch_size, want_loss)
-                    self._settle()
+                    for attempt in (0, 1):
+                        if method == 'gradient':
+                            loss = self._gradient_pass(d, node, y, loss_fn, batch_size, lr, adaptive_step, min_norm,
+                                                       max_norm, per_batch_update=(which == "fwd"))
+                        else:
+                            loss = self._site_update(d, node, y, loss_fn, batch_size, method, eps_, lr, adaptive_step,
+                                                     min_norm, max_norm, want_loss)
+                        if orthonormalize:
+                            (self.node_orthonormalize_right if reverse_gauge else self.node_orthonormalize_left)(node)
+                        if self._streams is not None:   # what the callbacks of this update may look at is queued
+                            self._nodes_ready = torch.cuda.Event()
+                            self._nodes_ready.record()
+                        if i + 1 < len(order) and method != 'gradient':
+                            # the next node's Gram matrix is queued before the host waits for the pivot flag
+                            # and before the callbacks take the host (see _speculate)
+                            nxt = order[i + 1]
+                            if not (nxt in self.node_indices and self.node_indices[nxt] == self.node_indices.get(last[other])):
+                                self._speculate(d, nxt, y, loss_fn, batch_size, want_loss)
+                        try:
+                            self._settle()
+                            break
+                        except _FactorisationAborted:
+                            # The single-launch factorisation gave up (its workgroups wait for each other, which needs
+                            # most of the device: a compute-unit mask or a partitioned device can starve it).  The update
+                            # has been undone: from here on this process factorises with one launch per panel, and the
+                            # node is done again.
+                            self._spec = None
+                            if attempt or ops.chol_mode(0) == 0:
+                                raise RuntimeError("ttk_chol_solve_f64: the factorisation was aborted (a workgroup waited "
+                                                   "for a tile beyond its limit); the update has been undone") from None
                 except torch.linalg.LinAlgError:
                     self._spec = None
                     if verbose and verbose > 0:

@@ -451,6 +451,40 @@ def test_cholesky_single_launch_gives_up_cleanly():
 
 
 @gpu
+def test_sweep_falls_back_when_single_launch_gives_up():
+    """A sweep whose single-launch factorisation aborts (here: patience cut to one poll; in the field: a compute-unit
+    mask that leaves its waiting workgroups without partners) undoes the update, switches this process to one launch
+    per panel and does the node again: same cores as a sweep that factorised that way from the start."""
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor.bregman import SquareBregFunction
+    from tensornetworksfork_amd.tensor.layers import TensorTrainLayer
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    x = [(torch.rand(700, 3, generator=g, dtype=torch.float64) * 2 - 1).to(dev) for _ in range(4)]
+    y = torch.randn(700, 1, generator=g, dtype=torch.float64).to(dev)
+
+    def sweep():
+        layer = TensorTrainLayer(4, 32, 3, output_shape=1, constrict_bond=False, seed=2).to(dev)
+        tn = layer.tensor_network
+        assert tn.accumulating_swipe(x, y, SquareBregFunction(), batch_size=128, num_swipes=1, method="ridge_cholesky",
+                                     eps=0.5, orthonormalize=True)
+        return [n.tensor.clone() for n in tn.main_nodes]
+
+    old = ops.chol_mode(0)
+    try:
+        ref = sweep()                      # one launch per panel throughout
+        ops.chol_mode(1)
+        ops.chol_mode(1000 + 1)            # the first middle site (order 3072) aborts its single launch
+        got = sweep()
+        assert ops.chol_mode(-2) == 0      # (a query) the process has switched
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    finally:
+        ops.chol_mode(1000)
+        ops.chol_mode(old)
+
+
+@gpu
 @pytest.mark.parametrize("m,n", [(192, 32), (6, 6), (36, 32), (17, 32), (12, 4), (5, 1), (1, 3), (300, 48), (64, 64)])
 def test_qr_matches_lapack(m, n):
     """One-workgroup Householder QR against torch.linalg.qr on the CPU (same sign convention)."""
