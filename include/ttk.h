@@ -339,6 +339,11 @@ int ttk_env_right_dense_f64(const double* R, const double* X, const double* core
                             int rr, int accumulate, void* stream);
 int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
                       void* stream);
+/* The same with the (S, C, n) result rows inside a wider tensor: row (s, c) starts at out + s ostride_s + c ostride_c
+ * (in doubles; ostride_c >= n, ostride_s >= C n), n contiguous.  The Jacobian rows J[s,c,a,(x,b)] of a conv filter
+ * node between two convolution bonds (tensor/layers.py:839-872) are written in place, one call per left channel a. */
+int ttk_lcontract_strided_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n,
+                              int64_t ostride_s, int64_t ostride_c, int accumulate, void* stream);
 int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
 int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
@@ -353,6 +358,24 @@ int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int
 int64_t ttk_rhs_feature_ws_bytes(int64_t S, int rl, int p, int rr);
 int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, double* b, int64_t S, int rl, int p, int rr,
                         int accumulate, void* ws, int64_t ws_bytes, void* stream);
+
+/* A train column between two convolution bonds (image_convolution_lanczos.py's CB > 0: the neighbouring filters of
+ * tensor/layers.py:839-872 leave ca channels on the left and cb on the right): its Jacobian is the sum of ca cb
+ * Khatri-Rao terms (L_a, G_ab, R_b), i.e. the contraction tensor/network.py:205-217, 258-291 carries out over the
+ * channel indices as well.  Small bonds (rl, rr <= 16), ca, cb <= 4, p <= 128 and p * 4 ceil(rr / 4) * rl * 8 <= 65536
+ * (ttk_bond_ok); one launch per half of the operator whatever ca cb is.  Layouts, all contiguous:
+ *   L (ca,S,C,rl)   G (ca,cb,S,p)   R (cb,S,rr)   v, b (rl,p,rr)   u, g (S,C)   GL (ca,S,rl)
+ *   ttk_bond_jv_f64:   u[s,c] (+)= sum_{a,b} sum_{l,pp,r} L_a[s,c,l] G_ab[s,pp] v[l,pp,r] R_b[s,r]
+ *   ttk_bond_gl_f64:   GL_a[s,l] = sum_c g[s,c] L_a[s,c,l]
+ *   ttk_bond_rhs_f64:  b[l,pp,r] (+)= sum_s sum_{a,b} GL_a[s,l] G_ab[s,pp] R_b[s,r]
+ * ws: ttk_bond_rhs_ws_bytes(S, rl, p, rr) bytes of slab partials (added in fixed order). */
+int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb);
+int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
+                    int p, int rr, int ca, int cb, int accumulate, void* stream);
+int ttk_bond_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, int ca, void* stream);
+int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr);
+int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
+                     int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 
 /* float32 matrix arithmetic for float32 models (image_convolution_lanczos_CIFAR10.py and CIFAR_lanczos_swipe.py
  * never set a dtype, so the reference contracts in float32: tensor/network.py:101-113, 788-789 on float32

@@ -66,11 +66,17 @@ SIGNATURES = {
     "ttk_gemm_rows_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_lcontract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_lcontract_strided_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
     "ttk_gemm_tn_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
     "ttk_rhs_feature_ws_bytes": (_i64, [_i64, _int, _int, _int]),
     "ttk_rhs_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_bond_ok": (_int, [_i64, _int, _int, _int, _int, _int, _int]),
+    "ttk_bond_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _int, _c_dp]),
+    "ttk_bond_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
+    "ttk_bond_rhs_ws_bytes": (_i64, [_i64, _int, _int, _int]),
+    "ttk_bond_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_gemm_rows_mm32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_mm32": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_ok": (_int, [_i64, _int, _int, _int, _int]),

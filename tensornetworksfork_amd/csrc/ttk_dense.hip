@@ -503,10 +503,12 @@ static EnvResDims env_resident_dims(int64_t S, int rl, int K, int lb, int nt) {
 // feature-contracted core (second stage of the left step of a site with many features; also
 // M[s,c,u] = L . (A . R) of a feature node's Jacobian).  HBM-bound on T.  A workgroup takes whole
 // samples (as many as fit 256 threads at one thread per (s, j), or one sample in several passes over j):
-// their L rows go through LDS, T is read coalesced along j.
+// their L rows go through LDS, T is read coalesced along j.  The output rows may sit inside a wider tensor
+// (sample stride ostride_s, output-index stride ostride_c, j contiguous): the rows J[s,c,a,(x,b)] of a conv
+// filter node between convolution bonds are written in place, one call per left channel a.
 __global__ __launch_bounds__(256) void lcontract_kernel(const double* __restrict__ L, const double* __restrict__ T,
                                                          double* __restrict__ out, int64_t S, int C, int rl, int n,
-                                                         int spb, int accumulate) {
+                                                         int spb, int accumulate, int64_t ostride_s, int64_t ostride_c) {
   extern __shared__ double Ls[];   // [spb][C * rl]
   const int64_t s0 = (int64_t)blockIdx.x * spb;
   const int ns = (int)min((int64_t)spb, S - s0);
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256) void lcontract_kernel(const double* __restrict
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c0 + c < C) {
-          double* o = out + ((s0 + sl) * C + c0 + c) * n + j;
+          double* o = out + (s0 + sl) * ostride_s + (c0 + c) * ostride_c + j;
           *o = accumulate ? *o + acc[c] : acc[c];
         }
     }
@@ -1080,6 +1082,229 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
 }
 
 // ---------------------------------------------------------------------------------------
+// A column between two convolution bonds (tensor/layers.py:839-872: the left neighbour's filter leaves ca
+// channels, the right one's cb): its Jacobian is the sum of ca cb Khatri-Rao terms (L_a, G_ab, R_b), all of them
+// small.  Contracting the two SMALL indices around the features first keeps every term of the sum inside one
+// kernel: no (S, rl rr) intermediate, one launch per operator half whatever ca cb is.
+//
+// bond_jv_kernel:  u[s,c] = sum_a sum_l L_a[s,c,l] z_a[s,l],
+//                  z_a[s,l] = sum_b sum_p G_ab[s,p] Y_b[s,l,p],   Y_b[s,l,p] = sum_r v[l,p,r] R_b[s,r].
+//   A wave owns 16 samples.  Y_b[., ., p] is one MFMA tile (rows l, columns = the samples, K = r) whose result
+//   lane (sample, kq) holds l = kq + 4 t: the lane multiplies by ITS sample's G_ab[s,p] (ca loads that walk
+//   along p, so they stay in L1) and keeps z_a for its sample and its four l.  v sits in LDS as [p][r][l]
+//   (r zero-padded to a multiple of 4, lanes l >= rl read row rl - 1: those result rows are never used).
+//   The left environments close the sum: four partial sums per sample, added across the kq groups.
+// bond_gl_kernel:  GL_a[s,l] = sum_c g[s,c] L_a[s,c,l] for all a in one launch.
+// bond_rhs_kernel: b[l,p,r] = sum_s sum_a T_a[s,p,r] GL_a[s,l],    T_a[s,p,r] = sum_b G_ab[s,p] R_b[s,r].
+//   K of the MFMA is the left channel a (ca <= 4: one instruction per sample, feature tile and r): the A operand
+//   lane (feature, a) forms T_a from ITS feature's G_ab[s,p] (cb loads, 16 consecutive features per row: whole
+//   128-byte segments) and the wave-uniform R_b[s,r] (scalar loads); the B operand lane (a, l) is GL_a[s,l] as
+//   stored.  The 8 waves split the feature tiles and the r between them; a workgroup walks one slab of samples
+//   and leaves its partial sums for dense_reduce_wide_kernel.
+template <int KS, int CA>
+__global__ __launch_bounds__(512, 4) void bond_jv_kernel(const double* __restrict__ Lenv, const double* __restrict__ G,
+                                                         const double* __restrict__ R, const double* __restrict__ v,
+                                                         double* __restrict__ u, int64_t S, int C, int rl, int p, int rr,
+                                                         int cb, int accumulate) {
+  extern __shared__ double bond_vs[];   // [p][4 KS][rl]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int nv = p * 4 * KS * rl;
+  for (int e = threadIdx.x; e < nv; e += 512) {
+    const int l = e % rl, r = (e / rl) % (4 * KS), pp = e / (rl * 4 * KS);
+    bond_vs[e] = r < rr ? v[((int64_t)l * p + pp) * rr + r] : 0.0;
+  }
+  __syncthreads();
+  const int64_t s0 = ((int64_t)blockIdx.x * 8 + wave) * 16;
+  if (s0 >= S) return;
+  const int64_t s = s0 + li;
+  const bool live = s < S;
+  const int64_t sc = live ? s : S - 1;
+  const int lv = li < rl ? li : rl - 1;
+  const int64_t astride = (int64_t)cb * S * p;
+  const double* vrow = bond_vs + kq * rl + lv;
+  double z[CA][4];
+#pragma unroll
+  for (int a = 0; a < CA; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) z[a][t] = 0.0;
+  for (int b = 0; b < cb; ++b) {
+    double rb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int r = 4 * ks + kq;
+      rb[ks] = (live && r < rr) ? R[((int64_t)b * S + sc) * rr + r] : 0.0;
+    }
+    const double* g0 = G + ((int64_t)b * S + sc) * p;
+    // the lane's own G rows, eight features at a time: the loads of a chunk are issued together and used from
+    // registers (a row's cache line would not survive in L1 between single-feature visits)
+    int pp0 = 0;
+    for (; pp0 + 8 <= p; pp0 += 8) {
+      double gv[CA][8];
+#pragma unroll
+      for (int a = 0; a < CA; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[a][j] = g0[a * astride + pp0 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = MFMA_F64(vrow[((pp0 + j) * 4 * KS + 4 * ks) * rl], rb[ks], acc);
+#pragma unroll
+        for (int a = 0; a < CA; ++a)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) z[a][t] = fma(gv[a][j], acc[t], z[a][t]);
+      }
+    }
+    for (; pp0 < p; ++pp0) {
+      double gv[CA];
+#pragma unroll
+      for (int a = 0; a < CA; ++a) gv[a] = g0[a * astride + pp0];
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = MFMA_F64(vrow[(pp0 * 4 * KS + 4 * ks) * rl], rb[ks], acc);
+#pragma unroll
+      for (int a = 0; a < CA; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) z[a][t] = fma(gv[a], acc[t], z[a][t]);
+    }
+  }
+  for (int c = 0; c < C; ++c) {
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < CA; ++a) {
+      const double* lp = Lenv + (((int64_t)a * S + sc) * C + c) * rl;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int l = kq + 4 * t;
+        if (l < rl) acc = fma(lp[l], z[a][t], acc);
+      }
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (kq == 0 && live) u[s * C + c] = (accumulate ? u[s * C + c] : 0.0) + acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void bond_gl_kernel(const double* __restrict__ g, const double* __restrict__ Lenv,
+                                                      double* __restrict__ GL, int64_t S, int C, int rl, int ca) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)ca * S * rl) return;
+  const int l = (int)(i % rl);
+  const int64_t as = i / rl, s = as % S;
+  double acc = 0.0;
+  for (int c = 0; c < C; ++c) acc = fma(g[s * C + c], Lenv[(as * C + c) * rl + l], acc);
+  GL[i] = acc;
+}
+
+template <int NR>   // right-bond indices per wave; ptw feature tiles x 8 / ptw groups of NR right-bond indices = the 8 waves
+__global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restrict__ GL, const double* __restrict__ G,
+                                                       const double* __restrict__ R, double* __restrict__ partial, int64_t S,
+                                                       int rl, int p, int rr, int ca, int cb, int64_t slab, int ptw) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kq = lane >> 4;   // kq = the left channel a
+  const int pt = wave % ptw, r0 = (wave / ptw) * NR;
+  const int r0c = r0 + NR <= rr ? r0 : (rr - NR > 0 ? rr - NR : 0);
+  const int pp = pt * 16 + li;
+  const bool gok = kq < ca && pp < p, lok = kq < ca && li < rl;
+  const int64_t s_lo = (int64_t)blockIdx.x * slab;
+  const int64_t s_hi = s_lo + slab < S ? s_lo + slab : S;
+  const int64_t bstride = (int64_t)S * p;
+  const double* gp = G + (int64_t)(kq < ca ? kq : 0) * cb * bstride + (pp < p ? pp : p - 1);
+  const double* glp = GL + (int64_t)(kq < ca ? kq : 0) * S * rl + (li < rl ? li : rl - 1);
+  d4 acc[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  if (pt * 16 < p && r0 < rr) {
+    // channels past cb read channel 0 with a zero G factor, and the wave's NR right-bond indices start at r0c <= r0
+    // so that all of them exist (tiles below r0 belong to the neighbouring wave and are not stored): the loop over
+    // a sample has no branches
+    int64_t rof[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rof[b] = (int64_t)(b < cb ? b : 0) * S * rr + r0c;
+    double gn[4], gln;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + s_lo * p] : 0.0;
+    gln = lok ? glp[s_lo * rl] : 0.0;
+    for (int64_t s = s_lo; s < s_hi; ++s) {
+      // R_b[s, r] is the same for every lane of the wave: scalar loads, a scalar operand of the multiply-add
+      const double* rs = R + s * rr;
+      double rv[4][NR];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) rv[b][j] = rs[rof[b] + j];
+      double g[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) g[b] = gn[b];
+      const double glv = gln;
+      const int64_t sn = s + 1 < s_hi ? s + 1 : s;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + sn * p] : 0.0;
+      gln = lok ? glp[sn * rl] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        double t = g[0] * rv[0][j];
+#pragma unroll
+        for (int b = 1; b < 4; ++b) t = fma(g[b], rv[b][j], t);
+        acc[j] = MFMA_F64(t, glv, acc[j]);
+      }
+    }
+  }
+  const int64_t D = (int64_t)rl * p * rr;
+  double* out = partial + (int64_t)blockIdx.x * D;
+  if (pt * 16 < p && li < rl) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      if (r0c + j < r0 || r0c + j >= rr) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int po = pt * 16 + kq + 4 * t;
+        if (po < p) out[((int64_t)li * p + po) * rr + r0c + j] = acc[j][t];
+      }
+    }
+  }
+}
+
+// out[i] (+)= sum over the slabs of partial[slab][i] for many slabs and few outputs: 16 outputs x 16 slab groups per
+// workgroup, every thread's loads independent and in flight together, the 16 group sums added in fixed order
+__global__ __launch_bounds__(256) void dense_reduce_wide_kernel(const double* __restrict__ partial, int nslabs, int64_t n,
+                                                                double* __restrict__ out, int accumulate) {
+  __shared__ double part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
+  const int64_t src = idx < n ? idx : n - 1;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = g;
+  for (; k + 48 < nslabs; k += 64) {
+    a0 += partial[(int64_t)k * n + src];
+    a1 += partial[(int64_t)(k + 16) * n + src];
+    a2 += partial[(int64_t)(k + 32) * n + src];
+    a3 += partial[(int64_t)(k + 48) * n + src];
+  }
+  for (; k < nslabs; k += 16) a0 += partial[(int64_t)k * n + src];
+  part[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && idx < n) {
+    double acc = accumulate ? out[idx] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += part[q][o];
+    out[idx] = acc;
+  }
+}
+
+static bool bond_fits(int64_t S, int C, int rl, int p, int rr, int ca, int cb) {
+  return S >= 1 && C >= 1 && rl >= 1 && rl <= 16 && rr >= 1 && rr <= 16 && p >= 1 && p <= 128 && ca >= 1 && ca <= 4 &&
+         cb >= 1 && cb <= 4 && (int64_t)p * 4 * ((rr + 3) / 4) * rl * 8 <= 65536;
+}
+
+static int64_t bond_rhs_slabs(int64_t S) {
+  const int64_t n = (S + 31) / 32;
+  return n < 1024 ? n : 1024;
+}
+
+// ---------------------------------------------------------------------------------------
 // Front-ends that turn raw inputs into the per-site feature tensors the columns read.
 //
 // feature_map_kernel: the local feature maps of TNMLRegressor (models/tnml.py:11-23) for all N sites in one
@@ -1166,6 +1391,81 @@ int ttk_patchify(const void* img, int64_t S, int Cin, int H, int W, int k, int s
   return dense_status();
 }
 
+int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb) { return bond_fits(S, C, rl, p, rr, ca, cb) ? 1 : 0; }
+
+int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
+                    int p, int rr, int ca, int cb, int accumulate, void* stream) {
+  if (!L || !G || !R || !v || !u || !bond_fits(S, C, rl, p, rr, ca, cb)) return TTK_EINVAL;
+  const int ks = (rr + 3) / 4;
+  const dim3 grid((unsigned)((S + 127) / 128));
+  const size_t lds = (size_t)p * 4 * ks * rl * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+#define BOND_JV(KS_, CA_)                                                                                              \
+  hipLaunchKernelGGL((bond_jv_kernel<KS_, CA_>), grid, dim3(512), lds, st, L, G, R, v, u, S, C, rl, p, rr, cb, accumulate)
+#define BOND_JV_CA(KS_)                                                                                                \
+  switch (ca) {                                                                                                        \
+    case 1: BOND_JV(KS_, 1); break;                                                                                    \
+    case 2: BOND_JV(KS_, 2); break;                                                                                    \
+    case 3: BOND_JV(KS_, 3); break;                                                                                    \
+    default: BOND_JV(KS_, 4); break;                                                                                   \
+  }
+  switch (ks) {
+    case 1: BOND_JV_CA(1); break;
+    case 2: BOND_JV_CA(2); break;
+    case 3: BOND_JV_CA(3); break;
+    default: BOND_JV_CA(4); break;
+  }
+#undef BOND_JV_CA
+#undef BOND_JV
+  return dense_status();
+}
+
+int ttk_bond_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, int ca, void* stream) {
+  if (!g || !L || !GL || S < 1 || C < 1 || rl < 1 || ca < 1) return TTK_EINVAL;
+  const int64_t n = (int64_t)ca * S * rl;
+  hipLaunchKernelGGL(bond_gl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, L, GL, S, C, rl, ca);
+  return dense_status();
+}
+
+int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr) {
+  if (S < 1 || rl < 1 || p < 1 || rr < 1) return 0;
+  return bond_rhs_slabs(S) * (int64_t)rl * p * rr * (int64_t)sizeof(double);
+}
+
+int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
+                     int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+  if (!GL || !G || !R || !b || !ws || !bond_fits(S, 1, rl, p, rr, ca, cb)) return TTK_EINVAL;
+  if (ws_bytes < ttk_bond_rhs_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
+  const int64_t nslabs = bond_rhs_slabs(S);
+  const int64_t slab = (S + nslabs - 1) / nslabs;
+  const int64_t used = (S + slab - 1) / slab;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  const int ptw = p <= 16 ? 1 : p <= 32 ? 2 : p <= 64 ? 4 : 8;      // feature tiles (waves along p); 8 / ptw groups of r
+  const int nr = (rr + 8 / ptw - 1) / (8 / ptw);                    // right-bond indices per wave
+#define BOND_RHS(NR_)                                                                                                  \
+  hipLaunchKernelGGL(bond_rhs_kernel<NR_>, dim3((unsigned)used), dim3(512), 0, st, GL, G, R, partial, S, rl, p, rr, ca, cb, \
+                     slab, ptw)
+  switch (nr) {
+    case 1: BOND_RHS(1); break;
+    case 2: BOND_RHS(2); break;
+    case 3: BOND_RHS(3); break;
+    case 4: BOND_RHS(4); break;
+    case 5: BOND_RHS(5); break;
+    case 6: BOND_RHS(6); break;
+    case 7: BOND_RHS(7); break;
+    case 8: BOND_RHS(8); break;
+    default: BOND_RHS(16); break;
+  }
+#undef BOND_RHS
+  int rc = dense_status();
+  if (rc != TTK_OK) return rc;
+  const int64_t D = (int64_t)rl * p * rr;
+  hipLaunchKernelGGL(dense_reduce_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)partial,
+                     (int)used, D, b, accumulate);
+  return dense_status();
+}
+
 int ttk_conv_feature_f64(const double* X, const double* F, double* G, int64_t rows, int px, int nab, void* stream) {
   if (!X || !F || !G || rows < 1 || px < 1 || nab < 1) return TTK_EINVAL;
   const int RB = conv_feature_rows(px, nab);
@@ -1213,17 +1513,22 @@ int ttk_env_right_dense_mm32(const double* R, const double* X, const double* cor
   return env_right_dense_launch<float>(R, X, core, out, S, rl, p, rr, accumulate, stream);
 }
 
-int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
-                      void* stream) {
-  if (!L || !T || !out || S < 1 || C < 1 || rl < 1 || n < 1) return TTK_EINVAL;
+int ttk_lcontract_strided_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n,
+                              int64_t ostride_s, int64_t ostride_c, int accumulate, void* stream) {
+  if (!L || !T || !out || S < 1 || C < 1 || rl < 1 || n < 1 || ostride_c < n || ostride_s < (int64_t)C * n) return TTK_EINVAL;
   int spb = n >= 256 ? 1 : 256 / n;
   const int fit = (int)(48 * 1024 / ((size_t)C * rl * sizeof(double)));
   if (fit < 1) return TTK_EINVAL;
   if (spb > fit) spb = fit;
   const size_t lds = (size_t)spb * C * rl * sizeof(double);
   hipLaunchKernelGGL(lcontract_kernel, dim3((unsigned)((S + spb - 1) / spb)), dim3(256), lds, (hipStream_t)stream, L, T, out,
-                     S, C, rl, n, spb, accumulate);
+                     S, C, rl, n, spb, accumulate, ostride_s, ostride_c);
   return dense_status();
+}
+
+int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
+                      void* stream) {
+  return ttk_lcontract_strided_f64(L, T, out, S, C, rl, n, (int64_t)C * n, n, accumulate, stream);
 }
 
 static int patch_contract_check(const void* M, const void* X, const void* J, int64_t S, int C, int P, int px) {

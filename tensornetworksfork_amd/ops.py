@@ -674,6 +674,59 @@ def rhs_feature(L, X, R, g, out=None, mm32=False, GL=None):
     return b
 
 
+_bond_ws = {}
+
+
+def bond_supported(L, G, R):
+    """True when the conv-bond kernels take the stacked factors L (ca,S,C,rl), G (ca,cb,S,p), R (cb,S,rr) of a
+    column between two convolution bonds: contiguous float64 device tensors, small bonds, few channels."""
+    if not (L.is_cuda and L.dtype == F64 and G.dtype == F64 and R.dtype == F64):
+        return False
+    if not (L.is_contiguous() and G.is_contiguous() and R.is_contiguous()):
+        return False
+    ca, S, C, rl = L.shape
+    cb, p, rr = G.shape[1], G.shape[3], R.shape[2]
+    return S > 0 and bool(_lib.lib().ttk_bond_ok(S, C, rl, p, rr, ca, cb))
+
+
+def bond_jv(L, G, R, v, out=None):
+    """u (S,C) = sum_{a,b} L_a . (G_ab (x) R_b) . v for the ca cb Khatri-Rao terms of a column between two
+    convolution bonds, in one launch; with `out` given the result is added to it."""
+    ca, S, C, rl = L.shape
+    cb, p, rr = G.shape[1], G.shape[3], R.shape[2]
+    acc = out is not None
+    u = out if acc else torch.empty((S, C), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_bond_jv_f64(_chk(L, "L"), _chk(G, "G", (ca, cb, S, p)), _chk(R, "R", (cb, S, rr)),
+                                    _chk(v, "v", (rl, p, rr)), _chk(u, "u", (S, C)), S, C, rl, p, rr, ca, cb, int(acc),
+                                    _stream(L))
+    _lib.check(rc, "ttk_bond_jv")
+    return u
+
+
+def bond_rhs(L, G, R, g, out=None):
+    """b (rl,p,rr) = sum_s sum_{a,b} (g . L_a)[s,l] G_ab[s,p] R_b[s,r]: J^T g of a column between two convolution
+    bonds (one launch for g . L_a, one for the sum over samples and terms, one to add the slab partials)."""
+    ca, S, C, rl = L.shape
+    cb, p, rr = G.shape[1], G.shape[3], R.shape[2]
+    GL = torch.empty((ca, S, rl), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_bond_gl_f64(_chk(g, "g", (S, C)), _chk(L, "L"), GL.data_ptr(), S, C, rl, ca, _stream(L))
+    _lib.check(rc, "ttk_bond_gl")
+    nbytes = int(_lib.lib().ttk_bond_rhs_ws_bytes(S, rl, p, rr))
+    key = (L.device, nbytes)
+    ws = _bond_ws.get(key)
+    if ws is None:
+        _bond_ws.clear()
+        ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
+        _bond_ws[key] = ws
+    acc = out is not None
+    b = out if acc else torch.empty((rl, p, rr), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_bond_rhs_f64(GL.data_ptr(), _chk(G, "G", (ca, cb, S, p)), _chk(R, "R", (cb, S, rr)),
+                                     _chk(b, "b", (rl, p, rr)), S, rl, p, rr, ca, cb, int(acc), ws.data_ptr(), nbytes,
+                                     _stream(L))
+    _lib.check(rc, "ttk_bond_rhs")
+    return b
+
+
 def conv_feature(X, Fc):
     """G (ca, cb, S, P) = X (S, P, px) . Fc (ca, px, cb); X float64 or float32 (read as it is)."""
     S, P, px = X.shape
@@ -715,6 +768,22 @@ def lcontract(L, T, out=None):
                                       int(acc), _stream(L))
     _lib.check(rc, "ttk_lcontract_f64")
     return o
+
+
+def lcontract_into(L, T, J, a):
+    """J[s, c, a, :] = sum_l L[s,c,l] T[s,l,:]  for J (S, C, ca, n) contiguous: the rows of one left channel of a
+    conv filter node's Jacobian, written in place."""
+    S, C, rl = L.shape
+    n = T.shape[2]
+    ca = J.shape[2]
+    if not (J.is_contiguous() and J.dtype == F64 and J.is_cuda and tuple(J.shape) == (S, C, ca, n) and 0 <= a < ca):
+        raise _lib.TTKError("lcontract_into: expected a contiguous float64 device tensor (S, C, ca, n)")
+    if S == 0:
+        return J
+    rc = _lib.lib().ttk_lcontract_strided_f64(_chk(L, "L"), _chk(T, "T", (S, rl, n)), J.data_ptr() + 8 * a * n, S, C, rl, n,
+                                              C * ca * n, ca * n, 0, _stream(L))
+    _lib.check(rc, "ttk_lcontract_strided_f64")
+    return J
 
 
 def env_step_left_dense(E, X, core, out=None, mm32=False):

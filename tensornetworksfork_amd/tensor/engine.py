@@ -165,6 +165,7 @@ class LocalProblem:
         self.J = J
         self._Jt = None
         self.mm32 = False               # float32 matrix arithmetic on the many-feature route (set by the engine)
+        self.bond = None                # stacked (L, G, R) of a column between convolution bonds the bond kernels take
 
     # -- first order
     def _jt(self):
@@ -184,6 +185,8 @@ class LocalProblem:
                 return ops.rows_rhs(self.J.contiguous(), g.reshape(self.S, self.C).contiguous()).reshape(self.shape)
             # wider rows still: element-wise product + row sums (the library's tall-skinny matrix-vector kernels are slow)
             return (self._jt() * g.reshape(1, self.S * self.C)).sum(dim=1).reshape(self.shape)
+        if self.bond is not None:
+            return ops.bond_rhs(*self.bond, g.reshape(self.S, self.C).contiguous())
         out = None
         # terms of a convolution bond share their left environments (L_a for every b): g . L once per L
         shared = {}
@@ -223,6 +226,8 @@ class LocalProblem:
         if self.J is not None:
             return ops.rows_dot(self.J.contiguous(), v.reshape(self.D).contiguous())
         v = v.reshape(self.shape)
+        if self.bond is not None:
+            return ops.bond_jv(*self.bond, v.contiguous())
         u = None
         tmp = {}
         zs = {}
@@ -835,6 +840,8 @@ class ChainEngine(EngineBase):
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
             prob = LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
             prob.mm32 = self.mm32
+            if len(terms) > 1 and ops.bond_supported(L, G, R):
+                prob.bond = (L, G, R)
             return prob
         # feature node: with M_ab[s,c,u] = L_a . (A . R_b) (a row GEMM, then the left environment's output index)
         #   conv filter    J[s,c,a,x,b]   = sum_patch M_ab[s,c,patch] X[s,patch,x]
@@ -857,6 +864,19 @@ class ChainEngine(EngineBase):
             ones = torch.ones((S, 1), dtype=F64, device=X.device)
             return LocalProblem(S, C, (u, dd, 1), Fc.reshape(u, dd, 1), back, terms=[(M(0, 0).contiguous(), X, ones)])
         J = torch.empty((S, C, ca) + col.inner + (cb,), dtype=F64, device=X.device)
+        if col.kind == "conv" and ca * cb > 1:
+            # the patches are contracted before the left environments: Z[s,l,x,b] = sum_patch U_b[s,l,patch] X[s,patch,x]
+            # reads the image rows cb times (not ca cb times), and J[s,c,a,(x,b)] = sum_l L_a[s,c,l] Z[s,l,(x,b)] is one
+            # small contraction per left channel, written in place
+            px = col.inner[0]
+            Z = torch.empty((S, col.rl, 1, px, cb), dtype=F64, device=X.device)
+            for b in range(cb):
+                U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
+                ops.patch_contract(U, X, Z, 0, b)
+            Zf, Jf = Z.reshape(S, col.rl, px * cb), J.reshape(S, C, ca, px * cb)
+            for a in range(ca):
+                ops.lcontract_into(L[a], Zf, Jf, a)
+            return LocalProblem(S, C, (ca,) + col.inner + (cb,), Fc, back, J=J.reshape(S, C, -1))
         for b in range(cb):
             for a in range(ca):
                 if col.kind == "conv":

@@ -155,6 +155,11 @@ def lcontract(L, T, out=None):
     return r if out is None else out.add_(r)
 
 
+def lcontract_into(L, T, J, a):
+    J[:, :, a, :] = torch.einsum('scl,sln->scn', L, T)
+    return J
+
+
 def env_step_left_dense(E, X, core, out=None, mm32=False):
     return env_step_left(E, X, core, out=out)
 
@@ -210,6 +215,21 @@ def lhl(L, H, z):
     u = torch.einsum('scl,sl->sc', L, z)
     hu = torch.einsum('scd,sc->sd', H, u)
     return torch.einsum('scl,sc->sl', L, hu)
+
+
+def bond_supported(L, G, R):
+    return L.is_contiguous() and G.is_contiguous() and R.is_contiguous() and L.shape[3] <= 16 and R.shape[2] <= 16 \
+        and L.shape[0] <= 4 and R.shape[0] <= 4 and G.shape[3] <= 128
+
+
+def bond_jv(L, G, R, v, out=None):
+    u = torch.einsum('ascl,absp,lpr,bsr->sc', L, G, v, R)
+    return u if out is None else out.add_(u)
+
+
+def bond_rhs(L, G, R, g, out=None):
+    b = torch.einsum('sc,ascl,absp,bsr->lpr', g, L, G, R)
+    return b if out is None else out.add_(b)
 
 
 def cg_update(x, r, p, q, state):
@@ -318,7 +338,7 @@ def lanczos_finish(V, alphas, betas, stop, m_run, x0):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs lcontract_into").split()
 
 
 def install(monkeypatch):

@@ -920,3 +920,30 @@ def test_feature_maps_on_device():
     ref = [torch.stack([torch.cos(0.5 * math.pi * X[:, i]), torch.sin(0.5 * math.pi * X[:, i])], dim=-1) for i in range(7)]
     for a, b in zip(got, ref):
         assert G.rel_err(a, b) < 1e-15
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,p,rr,ca,cb", [(1000, 9, 10, 50, 10, 4, 4), (77, 1, 3, 17, 5, 2, 3), (64, 10, 16, 31, 16, 1, 4),
+                                                (129, 2, 1, 7, 13, 4, 1), (5, 3, 9, 128, 4, 3, 2), (4100, 1, 10, 50, 1, 4, 2)])
+def test_conv_bond_kernels_match_einsum(S, C, rl, p, rr, ca, cb):
+    """The one-launch halves of the operator of a column between convolution bonds against the plain sum over the
+    ca cb Khatri-Rao terms (float64 einsum on the device), plain and accumulating."""
+    from tensornetworksfork_amd import ops
+    gen = torch.Generator().manual_seed(S + 7 * p + ca)
+    dev = _dev()
+    mk = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=gen).to(dev)   # noqa: E731
+    L, Gf, R = mk(ca, S, C, rl), mk(ca, cb, S, p), mk(cb, S, rr)
+    v, g = mk(rl, p, rr), mk(S, C)
+    assert ops.bond_supported(L, Gf, R)
+    u_ref = torch.einsum('ascl,absp,lpr,bsr->sc', L, Gf, v, R)
+    u = ops.bond_jv(L, Gf, R, v)
+    assert G.rel_err(u, u_ref) < 1e-13
+    u2 = ops.bond_jv(L, Gf, R, v, out=u_ref.clone())
+    assert G.rel_err(u2, 2 * u_ref) < 1e-13
+    b_ref = torch.einsum('sc,ascl,absp,bsr->lpr', g, L, Gf, R)
+    b = ops.bond_rhs(L, Gf, R, g)
+    assert G.rel_err(b, b_ref) < 1e-12
+    b2 = ops.bond_rhs(L, Gf, R, g, out=b_ref.clone())
+    assert G.rel_err(b2, 2 * b_ref) < 1e-12
+    assert torch.equal(b, ops.bond_rhs(L, Gf, R, g))          # fixed order of the slab partials
+    assert not ops.bond_supported(mk(2, 8, 1, 17), mk(2, 2, 8, 5), mk(2, 8, 3))       # left bond beyond one tile
