@@ -377,6 +377,23 @@ int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr);
 int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
                      int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 
+/* A conv filter node between convolution bonds (its tensor F[a,x,b]; tensor/layers.py:839-872) in factored form.
+ * Its Jacobian rows are J[s,c,(a,k)] = sum_l L_a[s,c,l] Z[s,l,k] with k = (x,b) and
+ * Z[s,l,(x,b)] = sum_patch (A . R_b)[s,l,patch] X[s,patch,x] (ttk_gemm_rows + ttk_patch_contract); the products of an
+ * iterative solve (tensor/network.py:788-789 for this node) stream L and Z (ca C rl + rl n numbers per sample)
+ * instead of the C ca n numbers of the rows.  L (ca,S,C,rl), Z (S,rl,n), H (S,C,C), v / q / b (ca,n), u / g (S,C):
+ *   ttk_filter_matvec_f64:  q = J^T H J v        ttk_filter_jv_f64:  u = J v        ttk_filter_rhs_f64:  b = J^T g
+ * Extents: C <= 64, ca <= 4, rl <= 16, n <= 256 and one sample's factors within the LDS of a wave
+ * (ttk_filter_ok).  ws: ttk_filter_ws_bytes bytes of workgroup partial sums (added in fixed order). */
+int ttk_filter_ok(int64_t S, int C, int rl, int n, int ca);
+int64_t ttk_filter_ws_bytes(int64_t S, int C, int rl, int n, int ca);
+int ttk_filter_matvec_f64(const double* L, const double* Z, const double* H, const double* v, double* q, int64_t S, int C,
+                          int rl, int n, int ca, void* ws, int64_t ws_bytes, void* stream);
+int ttk_filter_jv_f64(const double* L, const double* Z, const double* v, double* u, int64_t S, int C, int rl, int n, int ca,
+                      void* stream);
+int ttk_filter_rhs_f64(const double* L, const double* Z, const double* g, double* b, int64_t S, int C, int rl, int n, int ca,
+                       void* ws, int64_t ws_bytes, void* stream);
+
 /* float32 matrix arithmetic for float32 models (image_convolution_lanczos_CIFAR10.py and CIFAR_lanczos_swipe.py
  * never set a dtype, so the reference contracts in float32: tensor/network.py:101-113, 788-789 on float32
  * nodes).  Same arguments, layouts and memory types (float64) as the entry points they are named after; the

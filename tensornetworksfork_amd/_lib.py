@@ -72,6 +72,11 @@ SIGNATURES = {
     "ttk_gemm_tn_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
     "ttk_rhs_feature_ws_bytes": (_i64, [_i64, _int, _int, _int]),
     "ttk_rhs_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_filter_ok": (_int, [_i64, _int, _int, _int, _int]),
+    "ttk_filter_ws_bytes": (_i64, [_i64, _int, _int, _int, _int]),
+    "ttk_filter_matvec_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_filter_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_filter_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_bond_ok": (_int, [_i64, _int, _int, _int, _int, _int, _int]),
     "ttk_bond_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_bond_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),

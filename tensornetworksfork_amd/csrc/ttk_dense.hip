@@ -1305,6 +1305,231 @@ static int64_t bond_rhs_slabs(int64_t S) {
 }
 
 // ---------------------------------------------------------------------------------------
+// The operator of a conv filter node between convolution bonds without its Jacobian rows.  The rows factor as
+//   J[s,c,(a,k)] = sum_l L_a[s,c,l] Z[s,l,k],   k = (x, b),   Z[s,l,(x,b)] = sum_patch (A . R_b)[s,l,patch] X[s,patch,x]
+// (tensor/layers.py:839-872 contracted with both environments), and rl n + ca C rl numbers per sample (Z and the
+// left environments) are several times fewer than the C ca n of the rows: every product of an iterative solve
+// streams the factors instead.  filter_hjv_kernel, one wave per sample, the sample's factors in the wave's own LDS:
+//   y[a,l]  = sum_k Z[l,k] v[a,k]            u[c]  = sum_{a,l} L_a[c,l] y[a,l]         (MODE 1 stores u and stops)
+//   hu[d]   = sum_c H[s,c,d] u[c]                                                      (MODE 2 starts here: hu = g[s])
+//   gl[a,l] = sum_c hu[c] L_a[c,l]           q[a,k] += sum_l gl[a,l] Z[l,k]
+// The two products with Z are MFMA tiles with the channel a as the column (one instruction does the work of 64
+// lane-serial multiply-adds: the kernel is bound by instruction issue otherwise, not by memory); q stays in the
+// accumulators over the samples of a wave, the waves of a workgroup add theirs in LDS and the workgroup sums go to
+// dense_reduce_wide_kernel.  The phases of a sample are wave-local: LDS operations of one wave
+// complete in order, so only the compiler has to be kept from moving them.
+static __device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// `doubles` consecutive numbers from memory into a wave's LDS image by LDS-DMA (a wave instruction moves 64 units
+// to a wave-uniform LDS base, lane i to base + i * unit): 16-byte units when `wide` (doubles even, source and image
+// 16-byte aligned), else 4-byte units.  Lanes past the end are masked off.
+static __device__ __forceinline__ void wave_dma_copy(const double* __restrict__ g, int doubles, double* lds, int lane,
+                                                     bool wide) {
+  const char* src = (const char*)g;
+  if (wide) {
+    const int units = doubles >> 1;
+    for (int it = 0; it * 64 < units; ++it) {
+      const int u = it * 64 + lane;
+      if (u < units)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)u * 16),
+                                         (void __attribute__((address_space(3)))*)((char*)lds + it * 1024), 16, 0, 0);
+    }
+  } else {
+    const int units = doubles * 2;
+    for (int it = 0; it * 64 < units; ++it) {
+      const int u = it * 64 + lane;
+      if (u < units)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)u * 4),
+                                         (void __attribute__((address_space(3)))*)((char*)lds + it * 256), 4, 0, 0);
+    }
+  }
+}
+
+template <int MODE, int NKT>   // NKT: 16-column tiles of q a wave keeps (n <= 16 NKT)
+__global__ __launch_bounds__(256) void filter_hjv_kernel(const double* __restrict__ Lenv, const double* __restrict__ Z,
+                                                         const double* __restrict__ H, const double* __restrict__ x,
+                                                         double* __restrict__ out, int64_t S, int C, int rl, int n, int ca,
+                                                         int nwaves) {
+  extern __shared__ __attribute__((aligned(16))) double fsm[];
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int na = ca * rl, ncl = C * rl, n4 = (n + 3) & ~3, zn = rl * n;
+  const bool hlds = C <= 16;
+  // per-wave images (16-byte aligned): Z [rl][n], L_a [C][rl] per a, H [C][C] when hlds
+  const int zreg = (zn + 1) & ~1, lreg = (ncl + 1) & ~1, hreg = hlds ? (C * C + 1) & ~1 : 0;
+  const int per_wave = (zreg + ca * lreg + hreg + 2 * na + ca * C + 2 * C + 1) & ~1;
+  const int vreg = (ca * n4 + 1) & ~1;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* vs = fsm;                                   // [ca][n4], zero beyond n   (MODE 0, 1)
+  double* Zs = fsm + vreg + wave * per_wave;
+  double* Ls = Zs + zreg;
+  double* Hs = Ls + ca * lreg;
+  double* ys = Hs + hreg;                             // [ca rl]
+  double* gs = ys + na;                               // [ca rl]
+  double* ps = gs + na;                               // [ca][C]
+  double* us = ps + ca * C;                           // [C]
+  double* hs = us + C;                                // [C]
+  if (MODE != 2) {
+    for (int e = threadIdx.x; e < ca * n4; e += 256) {
+      const int a = e / n4, k = e - a * n4;
+      vs[e] = k < n ? x[a * n + k] : 0.0;
+    }
+    __syncthreads();
+  }
+  d4 q[NKT];   // q[kt][t] of lane (a = li, kq): column 16 kt + kq + 4 t of row a
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) q[kt] = d4{0.0, 0.0, 0.0, 0.0};
+  const int gw = blockIdx.x * nwaves + wave;
+  const int64_t stride = (int64_t)gridDim.x * nwaves;
+  const int ksn = n4 >> 2, ksl = (rl + 3) >> 2, nkt = (n + 15) >> 4;
+  const int lrow = li < rl ? li : rl - 1;
+  if (wave < nwaves) {
+    // A sample's factors go straight to the wave's LDS images (LDS-DMA: no staging registers, all loads of the
+    // sample in flight together): one memory round trip per sample, hidden by the other waves of the CU.
+    const bool wide = ((zn | ncl | (hlds ? C * C : 0)) & 1) == 0;   // every block a whole number of 16-byte units
+    for (int64_t s = gw; s < S; s += stride) {
+      wave_dma_copy(Z + s * (int64_t)zn, zn, Zs, lane, wide);
+      for (int a = 0; a < ca; ++a) wave_dma_copy(Lenv + ((int64_t)a * S + s) * ncl, ncl, Ls + a * lreg, lane, wide);
+      if (MODE == 0 && hlds) wave_dma_copy(H + s * (int64_t)C * C, C * C, Hs, lane, wide);
+      double hrow = 0.0;
+      if (MODE == 2) hrow = x[s * C + min(lane, C - 1)];
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the images have landed
+      wave_lds_order();
+      if (MODE != 2) {
+        // y[a,l] = sum_k Z[l,k] v[a,k]: one MFMA tile (rows l, columns a), K = k
+        d4 yacc = {0.0, 0.0, 0.0, 0.0};
+        const double* zr = Zs + lrow * n;
+        const double* vr = vs + (li < ca ? li : 0) * n4;
+#pragma unroll 4
+        for (int ks = 0; ks < ksn; ++ks) {
+          const int k = 4 * ks + kq;
+          const double av = zr[k < n ? k : n - 1];
+          const double bv = li < ca ? vr[k] : 0.0;
+          yacc = MFMA_F64(av, bv, yacc);
+        }
+        if (li < ca) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (kq + 4 * t < rl) ys[li * rl + kq + 4 * t] = yacc[t];
+        }
+        wave_lds_order();
+        // u[c] = sum_a sum_l L_a[c,l] y[a,l]: one lane per (a, c), then the ca partial sums of a c
+        for (int o = lane; o < ca * C; o += 64) {
+          const int a = o / C;
+          const double* lr = Ls + a * lreg + (o - a * C) * rl;
+          const double* yr = ys + a * rl;
+          double acc = 0.0;
+#pragma unroll 4
+          for (int l = 0; l < rl; ++l) acc = fma(lr[l], yr[l], acc);
+          ps[o] = acc;
+        }
+        wave_lds_order();
+        if (lane < C) {
+          double acc = 0.0;
+          for (int a = 0; a < ca; ++a) acc += ps[a * C + lane];
+          if (MODE == 1)
+            out[s * C + lane] = acc;
+          else
+            us[lane] = acc;
+        }
+        wave_lds_order();
+        if (MODE == 1) continue;
+        if (lane < C) {
+          double acc = 0.0;
+          if (hlds) {
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) acc = fma(Hs[c * C + lane], us[c], acc);
+          } else {
+            const double* hp = H + s * (int64_t)C * C + lane;
+            for (int c = 0; c < C; ++c) acc = fma(hp[(int64_t)c * C], us[c], acc);
+          }
+          hrow = acc;
+        }
+      }
+      if (lane < C) hs[lane] = hrow;
+      wave_lds_order();
+      if (lane < na) {
+        const int a = lane / rl, l = lane - a * rl;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) acc = fma(hs[c], Ls[a * lreg + c * rl + l], acc);
+        gs[lane] = acc;
+      }
+      wave_lds_order();
+      // q[a,k] += sum_l gl[a,l] Z[l,k]: tiles with rows k, columns a, K = l
+      double gb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int l = 4 * ks + kq;
+        gb[ks] = (ks < ksl && li < ca && l < rl) ? gs[li * rl + l] : 0.0;
+      }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+          const int k = 16 * kt + li;
+          const double* zc = Zs + (k < n ? k : n - 1);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            if (ks < ksl) {
+              const int l = 4 * ks + kq;
+              q[kt] = MFMA_F64(zc[(l < rl ? l : rl - 1) * n], gb[ks], q[kt]);
+            }
+          }
+        }
+      }
+      wave_lds_order();
+    }
+  }
+  if (MODE == 1) return;
+  // the waves' sums, added in wave order; the wave regions are free (all waves are past their samples)
+  __syncthreads();
+  double* red = fsm + vreg;   // [nwaves][ca n]
+  if (wave < nwaves && li < ca) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 16 * kt + kq + 4 * t;
+        if (k < n) red[wave * ca * n + li * n + k] = q[kt][t];
+      }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ca * n; e += 256) {
+    double acc = 0.0;
+    for (int w = 0; w < nwaves; ++w) acc += red[w * ca * n + e];
+    out[(int64_t)blockIdx.x * ca * n + e] = acc;
+  }
+}
+
+struct FilterDims {
+  int nwaves, grid;
+  size_t lds;
+};
+
+static bool filter_dims(int64_t S, int C, int rl, int n, int ca, FilterDims* d) {
+  if (S < 1 || C < 1 || C > 64 || rl < 1 || rl > 16 || n < 1 || n > 256 || ca < 1 || ca > 4) return false;
+  const size_t zreg = ((size_t)rl * n + 1) & ~(size_t)1, lreg = ((size_t)C * rl + 1) & ~(size_t)1;
+  const size_t hreg = C <= 16 ? ((size_t)C * C + 1) & ~(size_t)1 : 0;
+  const size_t per_wave =
+      ((zreg + ca * lreg + hreg + 2 * (size_t)ca * rl + (size_t)ca * C + 2 * (size_t)C + 1) & ~(size_t)1) * sizeof(double);
+  const size_t shared = (((size_t)ca * ((n + 3) & ~3) + 1) & ~(size_t)1) * sizeof(double);
+  if (per_wave < (size_t)ca * n * sizeof(double)) return false;   // the wave sums reuse the wave regions
+  int nw = 4;
+  while (nw > 0 && shared + nw * per_wave > 64 * 1024) --nw;
+  if (nw < 1) return false;
+  d->nwaves = nw;
+  d->lds = shared + nw * per_wave;
+  const int64_t want = (S + nw - 1) / nw;
+  const int per_cu = (int)((160 * 1024) / d->lds);                   // workgroups of a CU by LDS (at most 4 by waves)
+  const int64_t cap = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
+  d->grid = (int)(want < cap ? want : cap);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // Front-ends that turn raw inputs into the per-site feature tensors the columns read.
 //
 // feature_map_kernel: the local feature maps of TNMLRegressor (models/tnml.py:11-23) for all N sites in one
@@ -1389,6 +1614,73 @@ int ttk_patchify(const void* img, int64_t S, int Cin, int H, int W, int k, int s
     hipLaunchKernelGGL((patchify_kernel<float, double>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)img, S, Cin, H, W, k,
                        stride, OH, OW, (double*)out);
   return dense_status();
+}
+
+int ttk_filter_ok(int64_t S, int C, int rl, int n, int ca) {
+  FilterDims d;
+  return filter_dims(S, C, rl, n, ca, &d) ? 1 : 0;
+}
+
+int64_t ttk_filter_ws_bytes(int64_t S, int C, int rl, int n, int ca) {
+  FilterDims d;
+  if (!filter_dims(S, C, rl, n, ca, &d)) return 0;
+  return (int64_t)d.grid * ca * n * (int64_t)sizeof(double);
+}
+
+static int filter_launch(int mode, const double* L, const double* Z, const double* H, const double* x, double* out, int64_t S,
+                         int C, int rl, int n, int ca, void* ws, int64_t ws_bytes, void* stream) {
+  FilterDims d;
+  if (!L || !Z || !x || !out || !filter_dims(S, C, rl, n, ca, &d)) return TTK_EINVAL;
+  if (mode == 0 && !H) return TTK_EINVAL;
+  if (mode != 1 && (!ws || ws_bytes < ttk_filter_ws_bytes(S, C, rl, n, ca))) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+#define FILTER_GO(MODE_, NKT_, OUT_)                                                                                  \
+  hipLaunchKernelGGL((filter_hjv_kernel<MODE_, NKT_>), dim3(d.grid), dim3(256), d.lds, st, L, Z, H, x, OUT_, S, C, rl, n, ca, \
+                     d.nwaves)
+#define FILTER_NKT(MODE_)                                                                                              \
+  {                                                                                                                    \
+    const int nkt = (n + 15) / 16;                                                                                     \
+    if (nkt <= 2)                                                                                                      \
+      FILTER_GO(MODE_, 2, partial);                                                                                    \
+    else if (nkt <= 5)                                                                                                 \
+      FILTER_GO(MODE_, 5, partial);                                                                                    \
+    else if (nkt <= 8)                                                                                                 \
+      FILTER_GO(MODE_, 8, partial);                                                                                    \
+    else if (nkt <= 13)                                                                                                \
+      FILTER_GO(MODE_, 13, partial);                                                                                   \
+    else                                                                                                               \
+      FILTER_GO(MODE_, 16, partial);                                                                                   \
+  }
+  if (mode == 0)
+    FILTER_NKT(0)
+  else if (mode == 1)
+    FILTER_GO(1, 1, out);
+  else
+    FILTER_NKT(2)
+#undef FILTER_NKT
+#undef FILTER_GO
+  int rc = dense_status();
+  if (rc != TTK_OK || mode == 1) return rc;
+  const int64_t D = (int64_t)ca * n;
+  hipLaunchKernelGGL(dense_reduce_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)partial, d.grid, D,
+                     out, 0);
+  return dense_status();
+}
+
+int ttk_filter_matvec_f64(const double* L, const double* Z, const double* H, const double* v, double* q, int64_t S, int C,
+                          int rl, int n, int ca, void* ws, int64_t ws_bytes, void* stream) {
+  return filter_launch(0, L, Z, H, v, q, S, C, rl, n, ca, ws, ws_bytes, stream);
+}
+
+int ttk_filter_jv_f64(const double* L, const double* Z, const double* v, double* u, int64_t S, int C, int rl, int n, int ca,
+                      void* stream) {
+  return filter_launch(1, L, Z, nullptr, v, u, S, C, rl, n, ca, nullptr, 0, stream);
+}
+
+int ttk_filter_rhs_f64(const double* L, const double* Z, const double* g, double* b, int64_t S, int C, int rl, int n, int ca,
+                       void* ws, int64_t ws_bytes, void* stream) {
+  return filter_launch(2, L, Z, nullptr, g, b, S, C, rl, n, ca, ws, ws_bytes, stream);
 }
 
 int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb) { return bond_fits(S, C, rl, p, rr, ca, cb) ? 1 : 0; }

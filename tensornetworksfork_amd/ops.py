@@ -674,6 +674,66 @@ def rhs_feature(L, X, R, g, out=None, mm32=False, GL=None):
     return b
 
 
+_filter_ws = {}
+
+
+def filter_supported(L, Z):
+    """True when the factored filter-node kernels take L (ca,S,C,rl) and Z (S,rl,n) (contiguous float64 device
+    tensors whose per-sample factors fit the LDS of a wave)."""
+    if not (L.is_cuda and L.dtype == F64 and Z.dtype == F64 and L.is_contiguous() and Z.is_contiguous()):
+        return False
+    ca, S, C, rl = L.shape
+    return S > 0 and bool(_lib.lib().ttk_filter_ok(S, C, rl, Z.shape[2], ca))
+
+
+def _filter_workspace(L, n):
+    ca, S, C, rl = L.shape
+    nbytes = int(_lib.lib().ttk_filter_ws_bytes(S, C, rl, n, ca))
+    if nbytes <= 0:
+        raise _lib.TTKError("ttk_filter_ws_bytes: extents not supported")
+    key = (L.device, nbytes)
+    ws = _filter_ws.get(key)
+    if ws is None:
+        _filter_ws.clear()
+        ws = _filter_ws[key] = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
+    return ws, nbytes
+
+
+def filter_matvec(L, Z, H, v):
+    """q (ca n,) = J^T H J v for the rows J[s,c,(a,k)] = sum_l L[a,s,c,l] Z[s,l,k], never formed."""
+    ca, S, C, rl = L.shape
+    n = Z.shape[2]
+    ws, nbytes = _filter_workspace(L, n)
+    q = torch.empty((ca * n,), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_filter_matvec_f64(_chk(L, "L"), _chk(Z, "Z", (S, rl, n)), _chk(H, "H", (S, C, C)), _chk(v, "v", (ca * n,)),
+                                          q.data_ptr(), S, C, rl, n, ca, ws.data_ptr(), nbytes, _stream(L))
+    _lib.check(rc, "ttk_filter_matvec_f64")
+    return q
+
+
+def filter_jv(L, Z, v):
+    """u (S, C) = J v for the factored rows of filter_matvec."""
+    ca, S, C, rl = L.shape
+    n = Z.shape[2]
+    u = torch.empty((S, C), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_filter_jv_f64(_chk(L, "L"), _chk(Z, "Z", (S, rl, n)), _chk(v, "v", (ca * n,)), u.data_ptr(), S, C, rl, n,
+                                      ca, _stream(L))
+    _lib.check(rc, "ttk_filter_jv_f64")
+    return u
+
+
+def filter_rhs(L, Z, g):
+    """b (ca n,) = J^T g for the factored rows of filter_matvec."""
+    ca, S, C, rl = L.shape
+    n = Z.shape[2]
+    ws, nbytes = _filter_workspace(L, n)
+    b = torch.empty((ca * n,), dtype=F64, device=L.device)
+    rc = _lib.lib().ttk_filter_rhs_f64(_chk(L, "L"), _chk(Z, "Z", (S, rl, n)), _chk(g, "g", (S, C)), b.data_ptr(), S, C, rl, n, ca,
+                                       ws.data_ptr(), nbytes, _stream(L))
+    _lib.check(rc, "ttk_filter_rhs_f64")
+    return b
+
+
 _bond_ws = {}
 
 

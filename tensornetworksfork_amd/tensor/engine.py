@@ -153,7 +153,7 @@ class LocalProblem:
     Jacobian, or explicit Jacobian rows J (S,C,D).  `core` is the node's tensor in canonical
     (flattened) order; `back` maps a canonical vector to the node's own layout."""
 
-    def __init__(self, S, C, shape, core, back, terms=None, J=None):
+    def __init__(self, S, C, shape, core, back, terms=None, J=None, fz=None):
         self.S, self.C = S, C
         self.shape = tuple(shape)       # canonical shape, prod = D
         self.D = 1
@@ -162,10 +162,24 @@ class LocalProblem:
         self.core = core
         self.back = back
         self.terms = terms
-        self.J = J
+        self._J = J
+        # (L (ca,S,C,rl), Z (S,rl,n)): rows J[s,c,(a,k)] = sum_l L_a[s,c,l] Z[s,l,k] kept as factors (a conv filter
+        # node between convolution bonds); the rows themselves are formed only when something asks for them
+        self.fz = fz
         self._Jt = None
         self.mm32 = False               # float32 matrix arithmetic on the many-feature route (set by the engine)
         self.bond = None                # stacked (L, G, R) of a column between convolution bonds the bond kernels take
+
+    @property
+    def J(self):
+        if self._J is None and self.fz is not None:
+            L, Z = self.fz
+            ca, S, C, _ = L.shape
+            J = torch.empty((S, C, ca, Z.shape[2]), dtype=F64, device=Z.device)
+            for a in range(ca):
+                ops.lcontract_into(L[a], Z, J, a)
+            self._J = J.reshape(S, C, -1)
+        return self._J
 
     # -- first order
     def _jt(self):
@@ -176,6 +190,8 @@ class LocalProblem:
 
     def rhs(self, g):
         """b = J^T g, canonical shape."""
+        if self.fz is not None:
+            return ops.filter_rhs(*self.fz, g.reshape(self.S, self.C).contiguous()).reshape(self.shape)
         if self.J is not None:
             if self.D <= DENSE_ROWS_KERNEL_MAX_D:
                 # explicit rows are a Khatri-Rao term with the rows as left factor and no other factor
@@ -223,6 +239,8 @@ class LocalProblem:
 
     def jv(self, v):
         """u[s,c] = J v."""
+        if self.fz is not None:
+            return ops.filter_jv(*self.fz, v.reshape(self.D).contiguous())
         if self.J is not None:
             return ops.rows_dot(self.J.contiguous(), v.reshape(self.D).contiguous())
         v = v.reshape(self.shape)
@@ -259,6 +277,10 @@ class LocalProblem:
             if ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
                 return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
+        if self.fz is not None and H.shape[1] == self.C:
+            Lf, Zf = self.fz
+            Hc = H.contiguous()
+            return lambda v: ops.filter_matvec(Lf, Zf, Hc, v.reshape(self.D).contiguous()).reshape(self.shape)
         if self.J is not None and H.shape[1] == self.C and ops.rows_matvec_supported(self.S, self.C, self.D):
             # explicit rows of a narrow node (conv filter): the whole operator in one pass over the rows
             J = self.J.contiguous()
@@ -863,7 +885,6 @@ class ChainEngine(EngineBase):
             u, dd = col.inner
             ones = torch.ones((S, 1), dtype=F64, device=X.device)
             return LocalProblem(S, C, (u, dd, 1), Fc.reshape(u, dd, 1), back, terms=[(M(0, 0).contiguous(), X, ones)])
-        J = torch.empty((S, C, ca) + col.inner + (cb,), dtype=F64, device=X.device)
         if col.kind == "conv" and ca * cb > 1:
             # the patches are contracted before the left environments: Z[s,l,x,b] = sum_patch U_b[s,l,patch] X[s,patch,x]
             # reads the image rows cb times (not ca cb times), and J[s,c,a,(x,b)] = sum_l L_a[s,c,l] Z[s,l,(x,b)] is one
@@ -873,10 +894,15 @@ class ChainEngine(EngineBase):
             for b in range(cb):
                 U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
                 ops.patch_contract(U, X, Z, 0, b)
-            Zf, Jf = Z.reshape(S, col.rl, px * cb), J.reshape(S, C, ca, px * cb)
+            Zf = Z.reshape(S, col.rl, px * cb)
+            if col.rl * px * cb + ca * C * col.rl < C * ca * px * cb and ops.filter_supported(L, Zf):
+                # the factors are fewer numbers than the rows: the solver's products stream them instead
+                return LocalProblem(S, C, (ca,) + col.inner + (cb,), Fc, back, fz=(L, Zf))
+            Jf = torch.empty((S, C, ca, px * cb), dtype=F64, device=X.device)
             for a in range(ca):
                 ops.lcontract_into(L[a], Zf, Jf, a)
-            return LocalProblem(S, C, (ca,) + col.inner + (cb,), Fc, back, J=J.reshape(S, C, -1))
+            return LocalProblem(S, C, (ca,) + col.inner + (cb,), Fc, back, J=Jf.reshape(S, C, -1))
+        J = torch.empty((S, C, ca) + col.inner + (cb,), dtype=F64, device=X.device)
         for b in range(cb):
             for a in range(ca):
                 if col.kind == "conv":

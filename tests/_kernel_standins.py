@@ -217,6 +217,23 @@ def lhl(L, H, z):
     return torch.einsum('scl,sc->sl', L, hu)
 
 
+def filter_supported(L, Z):
+    return L.is_contiguous() and Z.is_contiguous() and L.shape[0] * L.shape[3] <= 64 and Z.shape[2] <= 256
+
+
+def filter_jv(L, Z, v):
+    return torch.einsum('ascl,slk,ak->sc', L, Z, v.reshape(L.shape[0], -1))
+
+
+def filter_rhs(L, Z, g):
+    return torch.einsum('ascl,slk,sc->ak', L, Z, g).reshape(-1)
+
+
+def filter_matvec(L, Z, H, v):
+    u = filter_jv(L, Z, v)
+    return filter_rhs(L, Z, torch.einsum('scd,sc->sd', H, u))
+
+
 def bond_supported(L, G, R):
     return L.is_contiguous() and G.is_contiguous() and R.is_contiguous() and L.shape[3] <= 16 and R.shape[2] <= 16 \
         and L.shape[0] <= 4 and R.shape[0] <= 4 and G.shape[3] <= 128
@@ -338,7 +355,7 @@ def lanczos_finish(V, alphas, betas, stop, m_run, x0):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs lcontract_into").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
 
 
 def install(monkeypatch):

@@ -947,3 +947,35 @@ def test_conv_bond_kernels_match_einsum(S, C, rl, p, rr, ca, cb):
     assert G.rel_err(b2, 2 * b_ref) < 1e-12
     assert torch.equal(b, ops.bond_rhs(L, Gf, R, g))          # fixed order of the slab partials
     assert not ops.bond_supported(mk(2, 8, 1, 17), mk(2, 2, 8, 5), mk(2, 8, 3))       # left bond beyond one tile
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,n,ca", [(1000, 10, 10, 68, 4), (77, 1, 3, 5, 2), (4099, 9, 16, 196, 4), (5, 3, 7, 256, 1),
+                                          (300, 33, 12, 40, 3)])
+def test_factored_filter_operator_matches_rows(S, C, rl, n, ca):
+    """J^T H J v, J v and J^T g of a conv filter node between convolution bonds from the factors (L, Z) against the
+    same products on the explicit rows J[s,c,(a,k)] = sum_l L_a[s,c,l] Z[s,l,k] (float64 einsum on the device); the
+    rows written in place by the strided contraction are checked on the way."""
+    from tensornetworksfork_amd import ops
+    gen = torch.Generator().manual_seed(S + n + ca)
+    dev = _dev()
+    mk = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=gen).to(dev)   # noqa: E731
+    L, Z, v, g = mk(ca, S, C, rl), mk(S, rl, n), mk(ca * n), mk(S, C)
+    Hh = mk(S, C, C)
+    H = (Hh + Hh.transpose(1, 2)).contiguous()
+    assert ops.filter_supported(L, Z)
+    J = torch.einsum('ascl,slk->scak', L, Z).reshape(S, C, ca * n)
+    Jk = torch.empty((S, C, ca, n), dtype=torch.float64, device=dev)
+    for a in range(ca):
+        ops.lcontract_into(L[a].contiguous(), Z, Jk, a)
+    assert G.rel_err(Jk.reshape(S, C, -1), J) < 1e-13
+    u_ref = torch.einsum('scd,d->sc', J, v)
+    assert G.rel_err(ops.filter_jv(L, Z, v), u_ref) < 1e-12
+    b_ref = torch.einsum('scd,sc->d', J, g)
+    b = ops.filter_rhs(L, Z, g)
+    assert G.rel_err(b, b_ref) < 1e-12
+    q_ref = torch.einsum('scd,sc->d', J, torch.einsum('scd,sc->sd', H, u_ref))
+    q = ops.filter_matvec(L, Z, H, v)
+    assert G.rel_err(q, q_ref) < 1e-12
+    assert torch.equal(q, ops.filter_matvec(L, Z, H, v))          # fixed order of the partial sums
+    assert not ops.filter_supported(mk(4, 8, 2, 17), mk(8, 17, 5))              # ca rl beyond one wave
