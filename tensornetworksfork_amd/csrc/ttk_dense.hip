@@ -1089,11 +1089,13 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
 //
 // bond_jv_kernel:  u[s,c] = sum_a sum_l L_a[s,c,l] z_a[s,l],
 //                  z_a[s,l] = sum_b sum_p G_ab[s,p] Y_b[s,l,p],   Y_b[s,l,p] = sum_r v[l,p,r] R_b[s,r].
-//   A wave owns 16 samples.  Y_b[., ., p] is one MFMA tile (rows l, columns = the samples, K = r) whose result
-//   lane (sample, kq) holds l = kq + 4 t: the lane multiplies by ITS sample's G_ab[s,p] (ca loads that walk
-//   along p, so they stay in L1) and keeps z_a for its sample and its four l.  v sits in LDS as [p][r][l]
-//   (r zero-padded to a multiple of 4, lanes l >= rl read row rl - 1: those result rows are never used).
-//   The left environments close the sum: four partial sums per sample, added across the kq groups.
+//   A wave owns 16 samples.  For one l, Y_b[., l, 16 features] is one MFMA tile (rows = features, columns = the
+//   samples, K = r) whose result lane (sample, kq) holds four CONSECUTIVE features 16 pt + 4 kq + t (row i of the
+//   tile carries feature 4 (i & 3) + (i >> 2)): every G_ab[s,p] is loaded by exactly one lane, 32 contiguous bytes
+//   at a time, and multiplied in that lane; z_a[s,l] stays in the lane as a partial sum over its features and
+//   meets the other three kq groups once, at the end.  v sits in LDS as [l][r][p] (r zero-padded to a multiple
+//   of 4; features past p read p - 1 with a zero G factor).  z goes to memory (ca S rl numbers) and
+//   bond_u_kernel closes the sum with the left environments, read as one contiguous stream.
 // bond_gl_kernel:  GL_a[s,l] = sum_c g[s,c] L_a[s,c,l] for all a in one launch.
 // bond_rhs_kernel: b[l,p,r] = sum_s sum_a T_a[s,p,r] GL_a[s,l],    T_a[s,p,r] = sum_b G_ab[s,p] R_b[s,r].
 //   K of the MFMA is the left channel a (ca <= 4: one instruction per sample, feature tile and r): the A operand
@@ -1101,88 +1103,161 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
 //   128-byte segments) and the wave-uniform R_b[s,r] (scalar loads); the B operand lane (a, l) is GL_a[s,l] as
 //   stored.  The 8 waves split the feature tiles and the r between them; a workgroup walks one slab of samples
 //   and leaves its partial sums for dense_reduce_wide_kernel.
-template <int KS, int CA>
-__global__ __launch_bounds__(512, 4) void bond_jv_kernel(const double* __restrict__ Lenv, const double* __restrict__ G,
-                                                         const double* __restrict__ R, const double* __restrict__ v,
-                                                         double* __restrict__ u, int64_t S, int C, int rl, int p, int rr,
-                                                         int cb, int accumulate) {
-  extern __shared__ double bond_vs[];   // [p][4 KS][rl]
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int CA, int RLT>   // left channels; left-bond indices a lane keeps partial sums for (rl <= RLT)
+__global__ __launch_bounds__(256) void bond_jv_kernel(const double* __restrict__ G,
+                                                      const double* __restrict__ R, const double* __restrict__ v,
+                                                      double* __restrict__ zout, int64_t S, int rl, int p, int rr, int cb,
+                                                      int64_t gsa, int64_t gsb, int64_t gss) {
+  extern __shared__ double bond_vs[];   // [rl][4 ksn][p]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int nv = p * 4 * KS * rl;
-  for (int e = threadIdx.x; e < nv; e += 512) {
-    const int l = e % rl, r = (e / rl) % (4 * KS), pp = e / (rl * 4 * KS);
+  const int ksn = (rr + 3) >> 2, r4 = 4 * ksn;
+  const int nv = rl * r4 * p;
+  for (int e = threadIdx.x; e < nv; e += 256) {
+    const int pp = e % p, r = (e / p) % r4, l = e / (p * r4);
     bond_vs[e] = r < rr ? v[((int64_t)l * p + pp) * rr + r] : 0.0;
   }
   __syncthreads();
-  const int64_t s0 = ((int64_t)blockIdx.x * 8 + wave) * 16;
+  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
   if (s0 >= S) return;
   const int64_t s = s0 + li;
   const bool live = s < S;
   const int64_t sc = live ? s : S - 1;
-  const int lv = li < rl ? li : rl - 1;
-  const int64_t astride = (int64_t)cb * S * p;
-  const double* vrow = bond_vs + kq * rl + lv;
-  double z[CA][4];
+  const int64_t astride = gsa;
+  const int fo = 4 * (li & 3) + (li >> 2);   // the feature of tile row li
+  const int npt = (p + 15) >> 4;
+  double z[CA][RLT];
 #pragma unroll
   for (int a = 0; a < CA; ++a)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) z[a][t] = 0.0;
+    for (int l = 0; l < RLT; ++l) z[a][l] = 0.0;
   for (int b = 0; b < cb; ++b) {
-    double rb[KS];
+    double rb[4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int r = 4 * ks + kq;
       rb[ks] = (live && r < rr) ? R[((int64_t)b * S + sc) * rr + r] : 0.0;
     }
-    const double* g0 = G + ((int64_t)b * S + sc) * p;
-    // the lane's own G rows, eight features at a time: the loads of a chunk are issued together and used from
-    // registers (a row's cache line would not survive in L1 between single-feature visits)
-    int pp0 = 0;
-    for (; pp0 + 8 <= p; pp0 += 8) {
-      double gv[CA][8];
+    const double* g0 = G + b * gsb + sc * gss;
+    for (int pt = 0; pt < npt; ++pt) {
+      const int f0 = 16 * pt + 4 * kq;
+      double gv[CA][4];
+      if (f0 + 4 <= p) {
+        // 32 contiguous bytes of the lane's row per channel: two 16-byte loads (the rows are 8-byte aligned)
 #pragma unroll
-      for (int a = 0; a < CA; ++a)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gv[a][j] = g0[a * astride + pp0 + j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = MFMA_F64(vrow[((pp0 + j) * 4 * KS + 4 * ks) * rl], rb[ks], acc);
+        for (int a = 0; a < CA; ++a) {
+          const d2u* gp2 = (const d2u*)(g0 + a * astride + f0);
+          const d2u lo = gp2[0], hi = gp2[1];
+          gv[a][0] = lo[0];
+          gv[a][1] = lo[1];
+          gv[a][2] = hi[0];
+          gv[a][3] = hi[1];
+        }
+      } else {
 #pragma unroll
         for (int a = 0; a < CA; ++a)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) z[a][t] = fma(gv[a][j], acc[t], z[a][t]);
+          for (int t = 0; t < 4; ++t) {
+            const double gval = g0[a * astride + (f0 + t < p ? f0 + t : p - 1)];
+            gv[a][t] = f0 + t < p ? gval : 0.0;
+          }
       }
-    }
-    for (; pp0 < p; ++pp0) {
-      double gv[CA];
+      const int fa = 16 * pt + fo < p ? 16 * pt + fo : p - 1;
+      const double* vcol = bond_vs + kq * p + fa;
 #pragma unroll
-      for (int a = 0; a < CA; ++a) gv[a] = g0[a * astride + pp0];
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int l = 0; l < RLT; ++l) {
+        if (l < rl) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = MFMA_F64(vrow[(pp0 * 4 * KS + 4 * ks) * rl], rb[ks], acc);
+          for (int ks = 0; ks < 4; ++ks)
+            if (ks < ksn) acc = MFMA_F64(vcol[(l * r4 + 4 * ks) * p], rb[ks], acc);
 #pragma unroll
-      for (int a = 0; a < CA; ++a)
+          for (int a = 0; a < CA; ++a)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) z[a][t] = fma(gv[a], acc[t], z[a][t]);
+            for (int t = 0; t < 4; ++t) z[a][l] = fma(gv[a][t], acc[t], z[a][l]);
+        }
+      }
     }
   }
-  for (int c = 0; c < C; ++c) {
-    double acc = 0.0;
+  // the four feature groups of a sample meet; lane kq of the sample stores the l = kq, kq + 4, ...
 #pragma unroll
-    for (int a = 0; a < CA; ++a) {
-      const double* lp = Lenv + (((int64_t)a * S + sc) * C + c) * rl;
+  for (int a = 0; a < CA; ++a)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int l = kq + 4 * t;
-        if (l < rl) acc = fma(lp[l], z[a][t], acc);
-      }
+    for (int l = 0; l < RLT; ++l) {
+      double t = z[a][l];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      if (live && l < rl && (l & 3) == kq) zout[((int64_t)a * S + s) * rl + l] = t;
     }
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
-    if (kq == 0 && live) u[s * C + c] = (accumulate ? u[s * C + c] : 0.0) + acc;
+}
+
+// u[s,c] (+)= sum_a sum_l L_a[s,c,l] z_a[s,l]: the left environments close the sum of bond_jv_kernel.  One thread per
+// (s, c): a wave reads 64 consecutive rows of L (contiguous), z[s] is the same for the C threads of a sample.
+__global__ __launch_bounds__(256) void bond_u_kernel(const double* __restrict__ Lenv, const double* __restrict__ z,
+                                                     double* __restrict__ u, int64_t S, int C, int rl, int ca, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * C) return;
+  const int64_t s = i / C;
+  double a0 = 0.0, a1 = 0.0;
+  for (int a = 0; a < ca; ++a) {
+    const double* lp = Lenv + ((int64_t)a * S * C + i) * rl;
+    const double* zp = z + ((int64_t)a * S + s) * rl;
+    int l = 0;
+    for (; l + 2 <= rl; l += 2) {
+      a0 = fma(lp[l], zp[l], a0);
+      a1 = fma(lp[l + 1], zp[l + 1], a1);
+    }
+    if (l < rl) a0 = fma(lp[l], zp[l], a0);
+  }
+  u[i] = (accumulate ? u[i] : 0.0) + (a0 + a1);
+}
+
+// GL_a[s,l] = sum_c hu[s,c] L_a[s,c,l],  hu[s,d] = sum_c H[s,c,d] u[s,c],  u[s,c] = sum_a sum_l L_a[s,c,l] z_a[s,l]:
+// prediction, Hessian product and g . L between the two halves of the operator in one kernel; the left environments
+// come from memory once (the second pass over a workgroup's few samples hits L1).  A workgroup takes ns samples:
+// one thread per (s, c), then one per (s, a, l).
+__global__ __launch_bounds__(256) void bond_lhl_kernel(const double* __restrict__ Lenv, const double* __restrict__ H,
+                                                       const double* __restrict__ z, double* __restrict__ GL, int64_t S, int C,
+                                                       int rl, int ca, int ns) {
+  __shared__ double ub[256], hb[256];
+  const int64_t s0 = (int64_t)blockIdx.x * ns;
+  const int cnt = (int)min((int64_t)ns, S - s0);
+  const int t = threadIdx.x;
+  if (t < cnt * C) {
+    const int sl = t / C, c = t - sl * C;
+    const int64_t s = s0 + sl;
+    double a0 = 0.0, a1 = 0.0;
+    for (int a = 0; a < ca; ++a) {
+      const double* lp = Lenv + (((int64_t)a * S + s) * C + c) * rl;
+      const double* zp = z + ((int64_t)a * S + s) * rl;
+      int l = 0;
+      for (; l + 2 <= rl; l += 2) {
+        a0 = fma(lp[l], zp[l], a0);
+        a1 = fma(lp[l + 1], zp[l + 1], a1);
+      }
+      if (l < rl) a0 = fma(lp[l], zp[l], a0);
+    }
+    ub[t] = a0 + a1;
+  }
+  __syncthreads();
+  if (t < cnt * C) {
+    const int sl = t / C, d = t - sl * C;
+    const double* hp = H + (s0 + sl) * (int64_t)C * C + d;
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) acc = fma(hp[(int64_t)c * C], ub[sl * C + c], acc);
+    hb[t] = acc;
+  }
+  __syncthreads();
+  const int na = ca * rl;
+  if (t < cnt * na) {
+    const int sl = t / na, o = t - sl * na, a = o / rl, l = o - a * rl;
+    const int64_t s = s0 + sl;
+    const double* lp = Lenv + ((int64_t)a * S + s) * C * rl + l;
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) acc = fma(hb[sl * C + c], lp[(int64_t)c * rl], acc);
+    GL[((int64_t)a * S + s) * rl + l] = acc;
   }
 }
 
@@ -1200,7 +1275,8 @@ __global__ __launch_bounds__(256) void bond_gl_kernel(const double* __restrict__
 template <int NR>   // right-bond indices per wave; ptw feature tiles x 8 / ptw groups of NR right-bond indices = the 8 waves
 __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restrict__ GL, const double* __restrict__ G,
                                                        const double* __restrict__ R, double* __restrict__ partial, int64_t S,
-                                                       int rl, int p, int rr, int ca, int cb, int64_t slab, int ptw) {
+                                                       int rl, int p, int rr, int ca, int cb, int64_t slab, int ptw,
+                                                       int64_t gsa, int64_t gsb, int64_t gss) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kq = lane >> 4;   // kq = the left channel a
@@ -1210,8 +1286,8 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
   const bool gok = kq < ca && pp < p, lok = kq < ca && li < rl;
   const int64_t s_lo = (int64_t)blockIdx.x * slab;
   const int64_t s_hi = s_lo + slab < S ? s_lo + slab : S;
-  const int64_t bstride = (int64_t)S * p;
-  const double* gp = G + (int64_t)(kq < ca ? kq : 0) * cb * bstride + (pp < p ? pp : p - 1);
+  const int64_t bstride = gsb;
+  const double* gp = G + (int64_t)(kq < ca ? kq : 0) * gsa + (pp < p ? pp : p - 1);
   const double* glp = GL + (int64_t)(kq < ca ? kq : 0) * S * rl + (li < rl ? li : rl - 1);
   d4 acc[NR];
 #pragma unroll
@@ -1225,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
     for (int b = 0; b < 4; ++b) rof[b] = (int64_t)(b < cb ? b : 0) * S * rr + r0c;
     double gn[4], gln;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + s_lo * p] : 0.0;
+    for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + s_lo * gss] : 0.0;
     gln = lok ? glp[s_lo * rl] : 0.0;
     for (int64_t s = s_lo; s < s_hi; ++s) {
       // R_b[s, r] is the same for every lane of the wave: scalar loads, a scalar operand of the multiply-add
@@ -1241,7 +1317,7 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
       const double glv = gln;
       const int64_t sn = s + 1 < s_hi ? s + 1 : s;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + sn * p] : 0.0;
+      for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + sn * gss] : 0.0;
       gln = lok ? glp[sn * rl] : 0.0;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -1685,30 +1761,79 @@ int ttk_filter_rhs_f64(const double* L, const double* Z, const double* g, double
 
 int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb) { return bond_fits(S, C, rl, p, rr, ca, cb) ? 1 : 0; }
 
-int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
-                    int p, int rr, int ca, int cb, int accumulate, void* stream) {
-  if (!L || !G || !R || !v || !u || !bond_fits(S, C, rl, p, rr, ca, cb)) return TTK_EINVAL;
+// strides (in doubles) of the channel a, the channel b and the sample in G: (ca,cb,S,p) or sample-major (S,ca,cb,p)
+static void bond_g_strides(int sample_major, int64_t S, int p, int ca, int cb, int64_t* gsa, int64_t* gsb, int64_t* gss) {
+  if (sample_major) {
+    *gsa = (int64_t)cb * p, *gsb = p, *gss = (int64_t)ca * cb * p;
+  } else {
+    *gsa = (int64_t)cb * S * p, *gsb = S * p, *gss = p;
+  }
+}
+
+int64_t ttk_bond_jv_ws_bytes(int64_t S, int rl, int ca) {
+  if (S < 1 || rl < 1 || ca < 1) return 0;
+  return (int64_t)ca * S * rl * (int64_t)sizeof(double);
+}
+
+static int bond_z_launch(const double* G, const double* R, const double* v, double* z, int64_t S, int rl, int p, int rr, int ca,
+                         int cb, int g_sample_major, hipStream_t st) {
+  int64_t gsa, gsb, gss;
+  bond_g_strides(g_sample_major, S, p, ca, cb, &gsa, &gsb, &gss);
   const int ks = (rr + 3) / 4;
-  const dim3 grid((unsigned)((S + 127) / 128));
+  const dim3 grid((unsigned)((S + 63) / 64));
   const size_t lds = (size_t)p * 4 * ks * rl * sizeof(double);
-  hipStream_t st = (hipStream_t)stream;
-#define BOND_JV(KS_, CA_)                                                                                              \
-  hipLaunchKernelGGL((bond_jv_kernel<KS_, CA_>), grid, dim3(512), lds, st, L, G, R, v, u, S, C, rl, p, rr, cb, accumulate)
-#define BOND_JV_CA(KS_)                                                                                                \
-  switch (ca) {                                                                                                        \
-    case 1: BOND_JV(KS_, 1); break;                                                                                    \
-    case 2: BOND_JV(KS_, 2); break;                                                                                    \
-    case 3: BOND_JV(KS_, 3); break;                                                                                    \
-    default: BOND_JV(KS_, 4); break;                                                                                   \
+#define BOND_JV(CA_, RLT_)                                                                                             \
+  hipLaunchKernelGGL((bond_jv_kernel<CA_, RLT_>), grid, dim3(256), lds, st, G, R, v, z, S, rl, p, rr, cb, gsa, gsb, gss)
+#define BOND_JV_RL(CA_)                                                                                                \
+  {                                                                                                                    \
+    if (rl <= 4)                                                                                                       \
+      BOND_JV(CA_, 4);                                                                                                 \
+    else if (rl <= 8)                                                                                                  \
+      BOND_JV(CA_, 8);                                                                                                 \
+    else if (rl <= 12)                                                                                                 \
+      BOND_JV(CA_, 12);                                                                                                \
+    else                                                                                                               \
+      BOND_JV(CA_, 16);                                                                                                \
   }
-  switch (ks) {
-    case 1: BOND_JV_CA(1); break;
-    case 2: BOND_JV_CA(2); break;
-    case 3: BOND_JV_CA(3); break;
-    default: BOND_JV_CA(4); break;
+  switch (ca) {
+    case 1: BOND_JV_RL(1) break;
+    case 2: BOND_JV_RL(2) break;
+    case 3: BOND_JV_RL(3) break;
+    default: BOND_JV_RL(4) break;
   }
-#undef BOND_JV_CA
+#undef BOND_JV_RL
 #undef BOND_JV
+  return dense_status();
+}
+
+int ttk_bond_z_f64(const double* G, const double* R, const double* v, double* z, int64_t S, int rl, int p, int rr, int ca, int cb,
+                   int g_sample_major, void* stream) {
+  if (!G || !R || !v || !z || !bond_fits(S, 1, rl, p, rr, ca, cb)) return TTK_EINVAL;
+  return bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, g_sample_major, (hipStream_t)stream);
+}
+
+int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
+                    int p, int rr, int ca, int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes,
+                    void* stream) {
+  if (!L || !G || !R || !v || !u || !ws || !bond_fits(S, C, rl, p, rr, ca, cb)) return TTK_EINVAL;
+  if (ws_bytes < ttk_bond_jv_ws_bytes(S, rl, ca)) return TTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* z = (double*)ws;
+  int rc = bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, g_sample_major, st);
+  if (rc != TTK_OK) return rc;
+  const int64_t nu = S * C;
+  hipLaunchKernelGGL(bond_u_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, L, (const double*)z, u, S, C, rl, ca,
+                     accumulate);
+  return dense_status();
+}
+
+int ttk_bond_lhl_f64(const double* L, const double* H, const double* z, double* GL, int64_t S, int C, int rl, int ca,
+                     void* stream) {
+  if (!L || !H || !z || !GL || S < 1 || C < 1 || rl < 1 || ca < 1 || C > 256 || ca * rl > 256) return TTK_EINVAL;
+  const int per = C > ca * rl ? C : ca * rl;
+  const int ns = 256 / per;
+  hipLaunchKernelGGL(bond_lhl_kernel, dim3((unsigned)((S + ns - 1) / ns)), dim3(256), 0, (hipStream_t)stream, L, H, z, GL, S, C,
+                     rl, ca, ns);
   return dense_status();
 }
 
@@ -1725,8 +1850,10 @@ int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr) {
 }
 
 int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
-                     int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+                     int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
   if (!GL || !G || !R || !b || !ws || !bond_fits(S, 1, rl, p, rr, ca, cb)) return TTK_EINVAL;
+  int64_t gsa, gsb, gss;
+  bond_g_strides(g_sample_major, S, p, ca, cb, &gsa, &gsb, &gss);
   if (ws_bytes < ttk_bond_rhs_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
   const int64_t nslabs = bond_rhs_slabs(S);
   const int64_t slab = (S + nslabs - 1) / nslabs;
@@ -1737,7 +1864,7 @@ int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double*
   const int nr = (rr + 8 / ptw - 1) / (8 / ptw);                    // right-bond indices per wave
 #define BOND_RHS(NR_)                                                                                                  \
   hipLaunchKernelGGL(bond_rhs_kernel<NR_>, dim3((unsigned)used), dim3(512), 0, st, GL, G, R, partial, S, rl, p, rr, ca, cb, \
-                     slab, ptw)
+                     slab, ptw, gsa, gsb, gss)
   switch (nr) {
     case 1: BOND_RHS(1); break;
     case 2: BOND_RHS(2); break;

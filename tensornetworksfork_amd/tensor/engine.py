@@ -277,6 +277,10 @@ class LocalProblem:
             if ops.rhs_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1]):
                 return lambda v: ops.matvec(L, X, R, H, v.reshape(self.shape))
 
+        if self.bond is not None and H.shape[1] == self.C:
+            Lb, Gb, Rb = self.bond
+            Hb = H.contiguous()
+            return lambda v: ops.bond_matvec(Lb, Gb, Rb, Hb, v.reshape(self.shape).contiguous())
         if self.fz is not None and H.shape[1] == self.C:
             Lf, Zf = self.fz
             Hc = H.contiguous()
