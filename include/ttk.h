@@ -348,6 +348,15 @@ int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t 
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
 int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream);
+/* Z[s,c,x,b] = sum_patch M_b[s,c,patch] X[s,patch,x] for the nb channels b of a convolution bond in one pass over
+ * the image rows: M (nb,S,C,P), Z (S,C,px,nb) contiguous, X float64 / float32.  The patch contraction of a conv filter
+ * node between convolution bonds (tensor/layers.py:839-872) with c = the left bond index.  The image row and the nb
+ * blocks of a sample must fit 64 KiB of LDS (ttk_patch_contract_multi_ok). */
+int ttk_patch_contract_multi_ok(int C, int P, int px, int nb);
+int ttk_patch_contract_multi_f64(const double* M, const double* X, double* Z, int64_t S, int C, int P, int px, int nb,
+                                 void* stream);
+int ttk_patch_contract_multi_f32(const double* M, const float* X, double* Z, int64_t S, int C, int P, int px, int nb,
+                                 void* stream);
 int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream);
 
 /* Right-hand side / J^T u of a site with many features (16 <= p <= 256, rr <= 128, p + rr <= 280: two chunk

@@ -69,6 +69,9 @@ SIGNATURES = {
     "ttk_lcontract_strided_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
+    "ttk_patch_contract_multi_ok": (_int, [_int, _int, _int, _int]),
+    "ttk_patch_contract_multi_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_patch_contract_multi_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_gemm_tn_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
     "ttk_rhs_feature_ws_bytes": (_i64, [_i64, _int, _int, _int]),
     "ttk_rhs_feature_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),

@@ -538,20 +538,21 @@ __global__ __launch_bounds__(256) void lcontract_kernel(const double* __restrict
   }
 }
 
-// J[s,c,x] (+)= sum_p Mv[s,c,p] X[s,p,x], written with row stride jstride and column stride xstride (the
-// Jacobian rows of a conv filter node C_k[a,x,b] sit at J[s,c,a,x,b]).  One workgroup per sample: X[s]
-// and Mv[s] through LDS, one thread per (c, x).  HBM-bound on X.
+// J[s,c,x,b] (+)= sum_p Mv_b[s,c,p] X[s,p,x] for b < nb, written with sample stride jstride_s, row stride jstride_c,
+// column stride xstride and the nb results of a (c, x) side by side (the Jacobian rows of a conv filter node
+// C_k[a,x,b] sit at J[s,c,a,x,b]; with nb channels in one call the image rows are read once, not nb times).
+// Mv_b = Mv + b mstride_b.  One workgroup per sample: X[s] and the Mv_b[s] through LDS, one thread per (c, x, b).
+// HBM-bound on X and Mv.
 template <typename TI>
 __global__ __launch_bounds__(256) void patch_contract_kernel(const double* __restrict__ Mv, const TI* __restrict__ X,
                                                               double* __restrict__ J, int C, int P, int px,
                                                               int64_t jstride_s, int64_t jstride_c, int64_t xstride,
-                                                              int accumulate) {
+                                                              int accumulate, int nb, int64_t mstride_b) {
   extern __shared__ double smem[];
   double* Xs = smem;            // [P][px]
-  double* Ms = Xs + P * px;     // [C][P]
+  double* Ms = Xs + P * px;     // [nb][C][P]
   const int64_t s = blockIdx.x;
   const TI* xs = X + s * (int64_t)P * px;
-  const double* ms = Mv + s * (int64_t)C * P;
   // eight unconditional (clamped) loads per thread in flight; the image row first, it is the long one
   const int nx = P * px, nm = C * P;
   for (int k0 = threadIdx.x; k0 < nx; k0 += 256 * 8) {
@@ -562,18 +563,22 @@ __global__ __launch_bounds__(256) void patch_contract_kernel(const double* __res
     for (int u = 0; u < 8; ++u)
       if (k0 + 256 * u < nx) Xs[k0 + 256 * u] = (double)t[u];
   }
-  for (int k0 = threadIdx.x; k0 < nm; k0 += 256 * 4) {
-    double t[4];
+  for (int b = 0; b < nb; ++b) {
+    const double* ms = Mv + b * mstride_b + s * (int64_t)nm;
+    for (int k0 = threadIdx.x; k0 < nm; k0 += 256 * 4) {
+      double t[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = ms[min(k0 + 256 * u, nm - 1)];
+      for (int u = 0; u < 4; ++u) t[u] = ms[min(k0 + 256 * u, nm - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (k0 + 256 * u < nm) Ms[k0 + 256 * u] = t[u];
+      for (int u = 0; u < 4; ++u)
+        if (k0 + 256 * u < nm) Ms[b * nm + k0 + 256 * u] = t[u];
+    }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < C * px; o += 256) {
-    const int c = o / px, x = o - c * px;
-    const double* mrow = Ms + c * P;
+  for (int o = threadIdx.x; o < C * px * nb; o += 256) {
+    const int b = o % nb, cx = o / nb;
+    const int c = cx / px, x = cx - c * px;
+    const double* mrow = Ms + b * nm + c * P;
     const double* xcol = Xs + x;
     double a0 = 0.0, a1 = 0.0;   // two chains, LDS reads of four patches issued together
     int pp = 0;
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void patch_contract_kernel(const double* __res
     }
     for (; pp < P; ++pp) a0 += mrow[pp] * xcol[pp * px];
     const double acc = a0 + a1;
-    double* dst = J + s * jstride_s + c * jstride_c + x * xstride;
+    double* dst = J + s * jstride_s + c * jstride_c + x * xstride + b;
     *dst = accumulate ? *dst + acc : acc;
   }
 }
@@ -1661,6 +1666,18 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ im
   }
 }
 
+template <typename TI>
+static int patch_contract_launch(const double* M, const TI* X, double* J, int64_t S, int C, int P, int px, int nb,
+                                 int64_t mstride_b, int64_t jstride_s, int64_t jstride_c, int64_t xstride, int accumulate,
+                                 void* stream) {
+  if (!M || !X || !J || S < 1 || C < 1 || P < 1 || px < 1 || nb < 1) return TTK_EINVAL;
+  const size_t lds = ((size_t)P * px + (size_t)nb * C * P) * sizeof(double);
+  if (lds > 64 * 1024) return TTK_EINVAL;
+  hipLaunchKernelGGL(patch_contract_kernel<TI>, dim3((unsigned)S), dim3(256), lds, (hipStream_t)stream, M, X, J, C, P, px,
+                     jstride_s, jstride_c, xstride, accumulate, nb, mstride_b);
+  return dense_status();
+}
+
 extern "C" {
 
 int ttk_feature_map_f64(const double* X, int64_t S, int N, int kind, int p, double* out, void* stream) {
@@ -1950,30 +1967,30 @@ int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, 
   return ttk_lcontract_strided_f64(L, T, out, S, C, rl, n, (int64_t)C * n, n, accumulate, stream);
 }
 
-static int patch_contract_check(const void* M, const void* X, const void* J, int64_t S, int C, int P, int px) {
-  if (!M || !X || !J || S < 1 || C < 1 || P < 1 || px < 1) return TTK_EINVAL;
-  if (((size_t)P * px + (size_t)C * P) * sizeof(double) > 64 * 1024) return TTK_EINVAL;
-  return TTK_OK;
-}
-
 int ttk_patch_contract_f64(const double* M, const double* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream) {
-  const int rc = patch_contract_check(M, X, J, S, C, P, px);
-  if (rc != TTK_OK) return rc;
-  const size_t lds = ((size_t)P * px + (size_t)C * P) * sizeof(double);
-  hipLaunchKernelGGL(patch_contract_kernel<double>, dim3((unsigned)S), dim3(256), lds, (hipStream_t)stream, M, X, J, C, P, px,
-                     jstride_s, jstride_c, xstride, accumulate);
-  return dense_status();
+  return patch_contract_launch<double>(M, X, J, S, C, P, px, 1, 0, jstride_s, jstride_c, xstride, accumulate, stream);
 }
 
 int ttk_patch_contract_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int64_t jstride_s,
                            int64_t jstride_c, int64_t xstride, int accumulate, void* stream) {
-  const int rc = patch_contract_check(M, X, J, S, C, P, px);
-  if (rc != TTK_OK) return rc;
-  const size_t lds = ((size_t)P * px + (size_t)C * P) * sizeof(double);
-  hipLaunchKernelGGL(patch_contract_kernel<float>, dim3((unsigned)S), dim3(256), lds, (hipStream_t)stream, M, X, J, C, P, px,
-                     jstride_s, jstride_c, xstride, accumulate);
-  return dense_status();
+  return patch_contract_launch<float>(M, X, J, S, C, P, px, 1, 0, jstride_s, jstride_c, xstride, accumulate, stream);
+}
+
+int ttk_patch_contract_multi_ok(int C, int P, int px, int nb) {
+  return C >= 1 && P >= 1 && px >= 1 && nb >= 1 && ((size_t)P * px + (size_t)nb * C * P) * sizeof(double) <= 64 * 1024 ? 1 : 0;
+}
+
+int ttk_patch_contract_multi_f64(const double* M, const double* X, double* J, int64_t S, int C, int P, int px, int nb,
+                                 void* stream) {
+  return patch_contract_launch<double>(M, X, J, S, C, P, px, nb, S * (int64_t)C * P, (int64_t)C * px * nb, (int64_t)px * nb,
+                                       nb, 0, stream);
+}
+
+int ttk_patch_contract_multi_f32(const double* M, const float* X, double* J, int64_t S, int C, int P, int px, int nb,
+                                 void* stream) {
+  return patch_contract_launch<float>(M, X, J, S, C, P, px, nb, S * (int64_t)C * P, (int64_t)C * px * nb, (int64_t)px * nb, nb,
+                                      0, stream);
 }
 
 int ttk_gemm_tn_f64(const double* A, const double* B, double* Cm, int64_t n, int D1, int D2, int accumulate, void* stream) {

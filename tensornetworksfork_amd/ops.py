@@ -911,6 +911,23 @@ def patch_contract(M, X, J, a=0, b=0):
     return J
 
 
+def patch_contract_multi(M, X):
+    """Z (S, C, px, nb) = sum_p M[b,s,c,p] X[s,p,:] for M (nb, S, C, P): the nb channels in one pass over X, or None
+    when a sample's blocks do not fit the kernel's LDS (the caller then goes channel by channel)."""
+    nb, S, C, P = M.shape
+    px = X.shape[2]
+    if not bool(_lib.lib().ttk_patch_contract_multi_ok(C, P, px, nb)):
+        return None
+    if not (X.is_contiguous() and X.is_cuda and X.dtype in (F64, torch.float32)):
+        raise _lib.TTKError("patch_contract_multi: expected a contiguous float64 / float32 device tensor X")
+    Z = torch.empty((S, C, px, nb), dtype=F64, device=M.device)
+    if S == 0:
+        return Z
+    fn = _lib.lib().ttk_patch_contract_multi_f64 if X.dtype == F64 else _lib.lib().ttk_patch_contract_multi_f32
+    _lib.check(fn(_chk(M, "M"), X.data_ptr(), Z.data_ptr(), S, C, P, px, nb, _stream(M)), "ttk_patch_contract_multi")
+    return Z
+
+
 def gemm_tn(A, B, out=None):
     """(D1, D2) (+)= A^T B for A (n, D1), B (n, D2)."""
     n, D1 = A.shape

@@ -894,10 +894,16 @@ class ChainEngine(EngineBase):
             # reads the image rows cb times (not ca cb times), and J[s,c,a,(x,b)] = sum_l L_a[s,c,l] Z[s,l,(x,b)] is one
             # small contraction per left channel, written in place
             px = col.inner[0]
-            Z = torch.empty((S, col.rl, 1, px, cb), dtype=F64, device=X.device)
-            for b in range(cb):
-                U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
-                ops.patch_contract(U, X, Z, 0, b)
+            Z = None
+            if R.is_contiguous():
+                # U_b = A . R_b for all b as one row GEMM over the stacked right environments, the patches in one pass
+                U = ops.gemm_rows(R.reshape(cb * S, -1), A2, col.rl * col.p, bmode=2, mm32=self.mm32)
+                Z = ops.patch_contract_multi(U.reshape(cb, S, col.rl, col.p), X)
+            if Z is None:
+                Z = torch.empty((S, col.rl, 1, px, cb), dtype=F64, device=X.device)
+                for b in range(cb):
+                    U = ops.gemm_rows(R[b], A2, col.rl * col.p, bmode=2, mm32=self.mm32).reshape(S, col.rl, col.p)
+                    ops.patch_contract(U, X, Z, 0, b)
             Zf = Z.reshape(S, col.rl, px * cb)
             if col.rl * px * cb + ca * C * col.rl < C * ca * px * cb and ops.filter_supported(L, Zf):
                 # the factors are fewer numbers than the rows: the solver's products stream them instead

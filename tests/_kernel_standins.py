@@ -169,6 +169,10 @@ def patch_contract(M, X, J, a=0, b=0):
     return J
 
 
+def patch_contract_multi(M, X):
+    return torch.einsum('bscp,spx->scxb', M, X.to(F64)).contiguous()
+
+
 def gemm_tn(A, B, out=None):
     r = A.T @ B
     return r if out is None else out.add_(r)
@@ -360,7 +364,7 @@ def lanczos_finish(V, alphas, betas, stop, m_run, x0):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec patch_contract_multi lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
 
 
 def install(monkeypatch):

@@ -987,3 +987,26 @@ def test_factored_filter_operator_matches_rows(S, C, rl, n, ca):
     assert G.rel_err(q, q_ref) < 1e-12
     assert torch.equal(q, ops.filter_matvec(L, Z, H, v))          # fixed order of the partial sums
     assert not ops.filter_supported(mk(4, 8, 2, 17), mk(8, 17, 5))              # ca rl beyond one wave
+
+
+@gpu
+@pytest.mark.parametrize("S,C,P,px,nb,dt", [(300, 10, 50, 17, 4, torch.float64), (65, 3, 7, 5, 2, torch.float32),
+                                            (4, 16, 65, 49, 3, torch.float32), (129, 1, 4, 4, 1, torch.float64)])
+def test_patch_contract_all_channels_in_one_pass(S, C, P, px, nb, dt):
+    """The patch contraction for the nb channels of a convolution bond in one pass over the image rows against one
+    call per channel (same sums, same order: bit-equal) and against a float64 einsum."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(S + P)
+    M = torch.randn(nb, S, C, P, dtype=torch.float64, generator=gen).to(dev)
+    X = torch.randn(S, P, px, dtype=dt, generator=gen).to(dev)
+    Z = ops.patch_contract_multi(M, X)
+    assert Z is not None and tuple(Z.shape) == (S, C, px, nb)
+    ref = torch.einsum('bscp,spx->scxb', M, X.to(torch.float64))
+    assert G.rel_err(Z, ref) < 1e-13
+    Z1 = torch.empty((S, C, 1, px, nb), dtype=torch.float64, device=dev)
+    for b in range(nb):
+        ops.patch_contract(M[b].contiguous(), X, Z1, 0, b)
+    assert torch.equal(Z1.reshape(S, C, px, nb), Z)
+    assert ops.patch_contract_multi(torch.zeros(4, 2, 16, 100, dtype=torch.float64, device=dev),
+                                    torch.zeros(2, 100, 49, dtype=torch.float64, device=dev)) is None   # beyond the LDS
