@@ -125,7 +125,17 @@ def cg_variant(device, F, y, steps):
                          "avg_launch_us": avg_ms * 1e3, "flops_per_launch": it_flops,
                          "algorithmic_bytes_per_launch": it_bytes,
                          "hbm_gbs": it_bytes / (avg_ms * 1e-3) * 1e-9,
-                         "hbm_frac": it_bytes / (avg_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, "traffic": None}}
+                         "hbm_frac": it_bytes / (avg_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
+                         "traffic": _recorded_traffic("cg_traffic.json")}}
+
+
+def _recorded_traffic(name):
+    """Fabric bytes per launch of a kernel from the committed counter passes (profiles/<name>; rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def _timed_kernel(which, fn):
@@ -180,10 +190,12 @@ def lanczos_variant(device, F, y, steps=8, max_iter=100):
         tn.train_nodes = all_nodes
     S, D = F[0].shape[0], BOND * (DEGREE + 1) * BOND
     per = holder["dt"] / steps
+    roof = _mfma_roofline("matvec_fused_kernel<8,3,0>", 4.0 * S * D, mv_ms, FP64_MFMA_PEAK_TFLOPS,
+                          S * (BOND + DEGREE + 1 + BOND + 1) * 8.0)
+    roof["traffic"] = _recorded_traffic("cg_traffic.json")     # the same product kernel without the CG prologue
     return {"value": 1.0 / per, "unit": "core-updates/s", "ms_per_step": per * 1e3, "steps": steps, "max_iter": max_iter,
             "tol": 1e-6, "products_per_update": len(mv_ms) / steps, "us_per_iteration": per * 1e6 / (len(mv_ms) / steps),
-            "roofline": _mfma_roofline("matvec_fused_kernel<8,3,0>", 4.0 * S * D, mv_ms, FP64_MFMA_PEAK_TFLOPS,
-                                       S * (BOND + DEGREE + 1 + BOND + 1) * 8.0)}
+            "roofline": roof}
 
 
 def _conv_problem(device, S, patches, pixels, bond, dtype, conv_bond):
