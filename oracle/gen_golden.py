@@ -488,6 +488,73 @@ def gen_many_patches():
     gen_conv("p10_cb2_f32", 3, 10, 5, 4, 2, 3, 64, 54, dtype=torch.float32, lanczos_iters=3)
 
 
+def gen_conv_full_shape(tag, N, patches, pixels, r, CB, C, S, seed, lanczos_iters=4, dtype=torch.float64):
+    torch.set_default_dtype(dtype)
+    try:
+        _gen_conv_full_shape(tag, N, patches, pixels, r, CB, C, S, seed, lanczos_iters, dtype)
+    finally:
+        torch.set_default_dtype(torch.float64)
+
+
+def _gen_conv_full_shape(tag, N, patches, pixels, r, CB, C, S, seed, lanczos_iters, dtype):
+    """The image scripts' own column shapes (image_convolution_lanczos_MNIST.py:29-32,76: 50 patches of 17 pixels, bond
+    10, convolution bond 4, 9 trained logits) on a few samples.  The Gram matrices of such nodes are 5000 x 5000 and stay
+    out of the fixture: forward, loss, b and A v of every train node and the first two updates of a Lanczos sweep.
+    dtype=torch.float32: the CIFAR script's arithmetic (CIFAR_lanczos_swipe.py:35-38,68-108 never sets a dtype)."""
+    layer = _conv_layer(N, r, patches, pixels, C, CB, seed)
+    tn = layer.tensor_network
+    g = torch.Generator().manual_seed(seed + 100)
+    # patch rows as the scripts build them: a zero last row, a zero last column, a one in the corner; labels from a
+    # linear teacher; the loss weight the scripts' normalisation gives (1 / spread of the initial outputs)
+    x = torch.randn(S, patches, pixels, generator=g)
+    x[:, -1, :] = 0.0
+    x[:, :, -1] = 0.0
+    x[:, -1, -1] = 1.0
+    teacher = torch.randn(patches * pixels, C + 1, generator=g)
+    y = torch.nn.functional.one_hot((x.reshape(S, -1) @ teacher).argmax(dim=1), C + 1).to(dtype)
+    w = 1.0 / tn.forward(x, to_tensor=True).std().item()
+    d = {"dtype": np.array(str(dtype).replace("torch.", "")), "N": N, "patches": patches, "pixels": pixels, "r": r, "CB": CB, "C": C, "S": S, "seed": seed, "x": x, "y": y,
+         "w": w, "train_names": np.array([n.name for n in tn.train_nodes])}
+    for i, t in enumerate(_snap_train(tn)):
+        d[f"node{i}"] = t
+    make_loss = lambda kind: bregman.XEAutogradBregman(w=w)   # noqa: E731
+    loss_fn = make_loss("xe")
+    y_pred = tn.forward(x, to_tensor=True)
+    loss, gr, H = loss_fn.forward(y_pred, y)
+    d["y_pred"], d["loss"] = y_pred, loss
+    v_gen = torch.Generator().manual_seed(seed + 7)
+    for k, node in enumerate(tn.train_nodes):
+        v = torch.randn(node.tensor.shape, generator=v_gen)
+        pj = tn.get_J(node, gr)
+        coeff = torch.einsum(f"{pj['einsum']},{pj['node_ein']},{pj['dd_loss_ein']}->{pj['coeff_ein']}", pj['J'].tensor, v, H)
+        d[f"Av{k}"] = torch.einsum(f"{pj['einsum']},{pj['d_loss_ein']}->{pj['node_ein']}", pj['J'].tensor, coeff)
+        d[f"b{k}"] = torch.einsum(f"{pj['einsum']},{pj['d_loss_ein']}->{pj['node_ein']}", pj['J'].tensor, gr)
+        d[f"v{k}"] = v
+    # A Lanczos pass over the first two train nodes (filter C1 and core A1).  Further on the reference's un-ridged
+    # Gauss-Newton steps leave the basin on so few samples (loss 2.7, 2.3, 91, 2e3, 1e18, then a singular tridiagonal
+    # system), and its ridge_cholesky sweep does not run at this shape (get_A_b asks for 518 GB).
+    tn2 = _conv_layer(N, r, patches, pixels, C, CB, seed).tensor_network
+    tn2.train_nodes = tn2.train_nodes[:2]
+    snaps, losses = [], []
+    torch.manual_seed(seed + 5)
+    ok = tn2.lanczos_swipe(x, y, make_loss("xe"), batch_size=32, num_swipes=1, max_iter=lanczos_iters, tol=1e-6,
+                           loss_callback=lambda l: losses.append(l),
+                           block_callback=lambda NS, n: snaps.append(_snap_train(tn2)))
+    d["lanczos_ok"] = int(ok)
+    d["lanczos_losses"] = np.array(losses)
+    d["lanczos_num_updates"] = len(snaps)
+    d["lanczos_forward"] = tn2.forward(x, to_tensor=True)
+    for u, snap in enumerate(snaps):
+        for i, t in enumerate(snap):
+            d[f"lanczos_u{u}_node{i}"] = t
+    d["lanczos_max_iter"], d["lanczos_torch_seed"] = lanczos_iters, seed + 5
+    npz(f"convfull_{tag}", **d)
+
+
+if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_FULL_SHAPE", "1") == "1":
+    gen_conv_full_shape("mnist_r10_cb4", 3, 50, 17, 10, 4, 9, 96, 61, lanczos_iters=4)
+    gen_conv_full_shape("mnist_r24", 3, 50, 17, 24, -1, 9, 96, 62, lanczos_iters=4)
+    gen_conv_full_shape("cifar_r48_f32", 3, 65, 49, 48, -1, 9, 48, 63, lanczos_iters=4, dtype=torch.float32)
 if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_EXTRA", "1") == "1":
     gen_extra()
 if __name__ == "__main__" and os.environ.get("TTK_GOLDEN_MANY_PATCHES", "1") == "1":

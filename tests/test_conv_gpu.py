@@ -257,3 +257,58 @@ def check_random_conv(case, DEV):
 @pytest.mark.parametrize("case", _random_conv_cases())
 def test_random_conv_golden(case):
     check_random_conv(case, DEV)
+
+
+def check_full_shape(name, DEV):
+    """The image scripts' own column shapes on a few samples against the reference: the MNIST script's model (50
+    patches of 17 pixels, bond 10, convolution bond 4: the cores between convolution bonds take the bond kernels, the
+    middle filter its factored operator), the bond-24 model without a convolution bond, and the CIFAR shape (65
+    patches of 49 pixels, bond 48) in float32.  Forward, loss, b and A v of every train node and the first two
+    updates of a Lanczos sweep; tolerances as for the small fixtures (float32: 1e-4 on single contractions, 2e-2 along
+    the reference's float32 Krylov recurrence)."""
+    from tensornetworksfork_amd.tensor import bregman
+    from tensornetworksfork_amd.tensor.layers import TensorConvolutionTrainLayer
+    d = G.load(name)
+    dt = _dtype(d)
+    tol, stol = _tol(d, 1e-10, 1e-4), _tol(d, 1e-5, 2e-2)
+
+    def fresh():
+        torch.set_default_dtype(dt)
+        try:
+            torch.manual_seed(int(d["seed"]))
+            layer = TensorConvolutionTrainLayer(int(d["N"]), int(d["r"]), int(d["patches"]), int(d["pixels"]),
+                                                output_shape=int(d["C"]), convolution_bond=int(d["CB"]))
+        finally:
+            torch.set_default_dtype(torch.float64)
+        return layer.to(DEV).tensor_network
+    tn = fresh()
+    assert [n.name for n in tn.train_nodes] == [str(s) for s in d["train_names"]]
+    for i, n in enumerate(tn.train_nodes):
+        assert torch.equal(n.tensor.cpu(), _in(d, f"node{i}", "cpu")), "seeded initialisation differs from the reference's"
+    x, y = _in(d, "x", DEV), _in(d, "y", DEV)
+    loss_fn = bregman.XEAutogradBregman(w=float(d["w"]))
+    y_pred = tn.forward(x, to_tensor=True)
+    assert G.rel_err(y_pred, d["y_pred"]) < tol
+    loss, g, H = loss_fn.forward(y_pred, y)
+    assert G.rel_err(loss, d["loss"]) < tol
+    for k, node in enumerate(tn.train_nodes):
+        assert G.rel_err(tn.get_b(node, g), d[f"b{k}"]) < tol, node.name
+        assert G.rel_err(tn.matvec(node, _in(d, f"v{k}", DEV), H), d[f"Av{k}"]) < tol, node.name
+    tn2, losses, snaps = fresh(), [], []
+    tn2.train_nodes = tn2.train_nodes[:2]
+    torch.manual_seed(int(d["lanczos_torch_seed"]))
+    ok = tn2.lanczos_swipe(x, y, loss_fn, batch_size=32, num_swipes=1, max_iter=int(d["lanczos_max_iter"]), tol=1e-6,
+                           loss_callback=lambda l: losses.append(l),
+                           block_callback=lambda NS, n: snaps.append([t.tensor.detach().clone() for t in tn2.train_nodes]))
+    assert int(ok) == int(d["lanczos_ok"]) and len(snaps) == int(d["lanczos_num_updates"])
+    for u, snap in enumerate(snaps):
+        assert abs(losses[u] - d["lanczos_losses"][u]) <= stol * abs(d["lanczos_losses"][u]), u
+        for i, c in enumerate(snap):
+            assert G.rel_err(c, d[f"lanczos_u{u}_node{i}"]) < stol, (u, i)
+    assert G.rel_err(tn2.forward(x, to_tensor=True), d["lanczos_forward"]) < stol
+
+
+@gpu
+@pytest.mark.parametrize("name", G.names("convfull_"))
+def test_conv_full_shape_golden(name):
+    check_full_shape(name, DEV)

@@ -20,6 +20,11 @@ def test_conv_host_logic(name, cpu_kernels):
     conv.check_lanczos_sweep(name, "cpu")
 
 
+@pytest.mark.parametrize("name", G.names("convfull_"))
+def test_conv_full_shape_host_logic(name, cpu_kernels):
+    conv.check_full_shape(name, "cpu")
+
+
 @pytest.fixture
 def api(monkeypatch, cpu_kernels):
     from tests import test_api_gpu
