@@ -371,7 +371,7 @@ int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, doub
 /* A train column between two convolution bonds (image_convolution_lanczos.py's CB > 0: the neighbouring filters of
  * tensor/layers.py:839-872 leave ca channels on the left and cb on the right): its Jacobian is the sum of ca cb
  * Khatri-Rao terms (L_a, G_ab, R_b), i.e. the contraction tensor/network.py:205-217, 258-291 carries out over the
- * channel indices as well.  Small bonds (rl, rr <= 16), ca, cb <= 4, p <= 128 and p * 4 ceil(rr / 4) * rl * 8 <= 65536
+ * channel indices as well.  Small bonds (rl, rr <= 16), ca, cb <= 4, p <= 128, C <= 256 and p * 4 ceil(rr / 4) * rl * 8 <= 65536
  * (ttk_bond_ok); one launch per half of the operator whatever ca cb is.  Layouts, all contiguous:
  *   L (ca,S,C,rl)   G (ca,cb,S,p), or (S,ca,cb,p) with g_sample_major != 0 (a sample's ca cb feature rows side by
  *   side: the 16 samples of a wave then read one contiguous range instead of ca cb distant ones)

@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(256) void dense_reduce_wide_kernel(const double* __
 }
 
 static bool bond_fits(int64_t S, int C, int rl, int p, int rr, int ca, int cb) {
-  return S >= 1 && C >= 1 && rl >= 1 && rl <= 16 && rr >= 1 && rr <= 16 && p >= 1 && p <= 128 && ca >= 1 && ca <= 4 &&
+  return S >= 1 && C >= 1 && C <= 256 && rl >= 1 && rl <= 16 && rr >= 1 && rr <= 16 && p >= 1 && p <= 128 && ca >= 1 && ca <= 4 &&
          cb >= 1 && cb <= 4 && (int64_t)p * 4 * ((rr + 3) / 4) * rl * 8 <= 65536;
 }
 
