@@ -373,9 +373,7 @@ int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, doub
  * Khatri-Rao terms (L_a, G_ab, R_b), i.e. the contraction tensor/network.py:205-217, 258-291 carries out over the
  * channel indices as well.  Small bonds (rl, rr <= 16), ca, cb <= 4, p <= 128, C <= 256 and p * 4 ceil(rr / 4) * rl * 8 <= 65536
  * (ttk_bond_ok); one launch per half of the operator whatever ca cb is.  Layouts, all contiguous:
- *   L (ca,S,C,rl)   G (ca,cb,S,p), or (S,ca,cb,p) with g_sample_major != 0 (a sample's ca cb feature rows side by
- *   side: the 16 samples of a wave then read one contiguous range instead of ca cb distant ones)
- *   R (cb,S,rr)   v, b (rl,p,rr)   u, g (S,C)   GL (ca,S,rl)
+ *   L (ca,S,C,rl)   G (ca,cb,S,p)   R (cb,S,rr)   v, b (rl,p,rr)   u, g (S,C)   GL (ca,S,rl)
  *   ttk_bond_jv_f64:   u[s,c] (+)= sum_{a,b} sum_{l,pp,r} L_a[s,c,l] G_ab[s,pp] v[l,pp,r] R_b[s,r]
  *   ttk_bond_gl_f64:   GL_a[s,l] = sum_c g[s,c] L_a[s,c,l]
  *   ttk_bond_rhs_f64:  b[l,pp,r] (+)= sum_s sum_{a,b} GL_a[s,l] G_ab[s,pp] R_b[s,r]
@@ -385,8 +383,7 @@ int ttk_rhs_feature_f64(const double* GL, const double* X, const double* R, doub
 int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb);
 int64_t ttk_bond_jv_ws_bytes(int64_t S, int rl, int ca);
 int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
-                    int p, int rr, int ca, int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes,
-                    void* stream);
+                    int p, int rr, int ca, int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 int ttk_bond_gl_f64(const double* g, const double* L, double* GL, int64_t S, int C, int rl, int ca, void* stream);
 /* The two halves of the operator v -> J^T H J v of such a column (tensor/network.py:788-789) meet in the left bond:
  *   ttk_bond_z_f64:    z (ca,S,rl),  z_a[s,l] = sum_{b,pp,r} G_ab[s,pp] v[l,pp,r] R_b[s,r]   (first launch of ttk_bond_jv_f64)
@@ -394,12 +391,12 @@ int ttk_bond_gl_f64(const double* g, const double* L, double* GL, int64_t S, int
  * (prediction, Hessian product and g . L in one kernel: the left environments are read once); ttk_bond_rhs_f64
  * finishes.  H (S,C,C); C <= 256, ca rl <= 256. */
 int ttk_bond_z_f64(const double* G, const double* R, const double* v, double* z, int64_t S, int rl, int p, int rr, int ca, int cb,
-                   int g_sample_major, void* stream);
+                   void* stream);
 int ttk_bond_lhl_f64(const double* L, const double* H, const double* z, double* GL, int64_t S, int C, int rl, int ca,
                      void* stream);
 int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr);
 int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
-                     int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+                     int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 
 /* A conv filter node between convolution bonds (its tensor F[a,x,b]; tensor/layers.py:839-872) in factored form.
  * Its Jacobian rows are J[s,c,(a,k)] = sum_l L_a[s,c,l] Z[s,l,k] with k = (x,b) and

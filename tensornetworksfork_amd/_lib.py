@@ -81,13 +81,13 @@ SIGNATURES = {
     "ttk_filter_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_filter_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_bond_ok": (_int, [_i64, _int, _int, _int, _int, _int, _int]),
-    "ttk_bond_z_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
+    "ttk_bond_z_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_bond_lhl_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
     "ttk_bond_jv_ws_bytes": (_i64, [_i64, _int, _int]),
-    "ttk_bond_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_bond_jv_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_bond_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _c_dp]),
     "ttk_bond_rhs_ws_bytes": (_i64, [_i64, _int, _int, _int]),
-    "ttk_bond_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
+    "ttk_bond_rhs_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_gemm_rows_mm32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_mm32": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_ok": (_int, [_i64, _int, _int, _int, _int]),

@@ -1113,8 +1113,7 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int CA, int RLT>   // left channels; left-bond indices a lane keeps partial sums for (rl <= RLT)
 __global__ __launch_bounds__(256) void bond_jv_kernel(const double* __restrict__ G,
                                                       const double* __restrict__ R, const double* __restrict__ v,
-                                                      double* __restrict__ zout, int64_t S, int rl, int p, int rr, int cb,
-                                                      int64_t gsa, int64_t gsb, int64_t gss) {
+                                                      double* __restrict__ zout, int64_t S, int rl, int p, int rr, int cb) {
   extern __shared__ double bond_vs[];   // [rl][4 ksn][p]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1130,7 +1129,7 @@ __global__ __launch_bounds__(256) void bond_jv_kernel(const double* __restrict__
   const int64_t s = s0 + li;
   const bool live = s < S;
   const int64_t sc = live ? s : S - 1;
-  const int64_t astride = gsa;
+  const int64_t astride = (int64_t)cb * S * p;
   const int fo = 4 * (li & 3) + (li >> 2);   // the feature of tile row li
   const int npt = (p + 15) >> 4;
   double z[CA][RLT];
@@ -1145,7 +1144,7 @@ __global__ __launch_bounds__(256) void bond_jv_kernel(const double* __restrict__
       const int r = 4 * ks + kq;
       rb[ks] = (live && r < rr) ? R[((int64_t)b * S + sc) * rr + r] : 0.0;
     }
-    const double* g0 = G + b * gsb + sc * gss;
+    const double* g0 = G + ((int64_t)b * S + sc) * p;
     for (int pt = 0; pt < npt; ++pt) {
       const int f0 = 16 * pt + 4 * kq;
       double gv[CA][4];
@@ -1280,8 +1279,7 @@ __global__ __launch_bounds__(256) void bond_gl_kernel(const double* __restrict__
 template <int NR>   // right-bond indices per wave; ptw feature tiles x 8 / ptw groups of NR right-bond indices = the 8 waves
 __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restrict__ GL, const double* __restrict__ G,
                                                        const double* __restrict__ R, double* __restrict__ partial, int64_t S,
-                                                       int rl, int p, int rr, int ca, int cb, int64_t slab, int ptw,
-                                                       int64_t gsa, int64_t gsb, int64_t gss) {
+                                                       int rl, int p, int rr, int ca, int cb, int64_t slab, int ptw) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kq = lane >> 4;   // kq = the left channel a
@@ -1291,8 +1289,8 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
   const bool gok = kq < ca && pp < p, lok = kq < ca && li < rl;
   const int64_t s_lo = (int64_t)blockIdx.x * slab;
   const int64_t s_hi = s_lo + slab < S ? s_lo + slab : S;
-  const int64_t bstride = gsb;
-  const double* gp = G + (int64_t)(kq < ca ? kq : 0) * gsa + (pp < p ? pp : p - 1);
+  const int64_t bstride = (int64_t)S * p;
+  const double* gp = G + (int64_t)(kq < ca ? kq : 0) * cb * bstride + (pp < p ? pp : p - 1);
   const double* glp = GL + (int64_t)(kq < ca ? kq : 0) * S * rl + (li < rl ? li : rl - 1);
   d4 acc[NR];
 #pragma unroll
@@ -1306,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
     for (int b = 0; b < 4; ++b) rof[b] = (int64_t)(b < cb ? b : 0) * S * rr + r0c;
     double gn[4], gln;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + s_lo * gss] : 0.0;
+    for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + s_lo * p] : 0.0;
     gln = lok ? glp[s_lo * rl] : 0.0;
     for (int64_t s = s_lo; s < s_hi; ++s) {
       // R_b[s, r] is the same for every lane of the wave: scalar loads, a scalar operand of the multiply-add
@@ -1322,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
       const double glv = gln;
       const int64_t sn = s + 1 < s_hi ? s + 1 : s;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + sn * gss] : 0.0;
+      for (int b = 0; b < 4; ++b) gn[b] = (b < cb && gok) ? gp[b * bstride + sn * p] : 0.0;
       gln = lok ? glp[sn * rl] : 0.0;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -1778,29 +1776,18 @@ int ttk_filter_rhs_f64(const double* L, const double* Z, const double* g, double
 
 int ttk_bond_ok(int64_t S, int C, int rl, int p, int rr, int ca, int cb) { return bond_fits(S, C, rl, p, rr, ca, cb) ? 1 : 0; }
 
-// strides (in doubles) of the channel a, the channel b and the sample in G: (ca,cb,S,p) or sample-major (S,ca,cb,p)
-static void bond_g_strides(int sample_major, int64_t S, int p, int ca, int cb, int64_t* gsa, int64_t* gsb, int64_t* gss) {
-  if (sample_major) {
-    *gsa = (int64_t)cb * p, *gsb = p, *gss = (int64_t)ca * cb * p;
-  } else {
-    *gsa = (int64_t)cb * S * p, *gsb = S * p, *gss = p;
-  }
-}
-
 int64_t ttk_bond_jv_ws_bytes(int64_t S, int rl, int ca) {
   if (S < 1 || rl < 1 || ca < 1) return 0;
   return (int64_t)ca * S * rl * (int64_t)sizeof(double);
 }
 
 static int bond_z_launch(const double* G, const double* R, const double* v, double* z, int64_t S, int rl, int p, int rr, int ca,
-                         int cb, int g_sample_major, hipStream_t st) {
-  int64_t gsa, gsb, gss;
-  bond_g_strides(g_sample_major, S, p, ca, cb, &gsa, &gsb, &gss);
+                         int cb, hipStream_t st) {
   const int ks = (rr + 3) / 4;
   const dim3 grid((unsigned)((S + 63) / 64));
   const size_t lds = (size_t)p * 4 * ks * rl * sizeof(double);
 #define BOND_JV(CA_, RLT_)                                                                                             \
-  hipLaunchKernelGGL((bond_jv_kernel<CA_, RLT_>), grid, dim3(256), lds, st, G, R, v, z, S, rl, p, rr, cb, gsa, gsb, gss)
+  hipLaunchKernelGGL((bond_jv_kernel<CA_, RLT_>), grid, dim3(256), lds, st, G, R, v, z, S, rl, p, rr, cb)
 #define BOND_JV_RL(CA_)                                                                                                \
   {                                                                                                                    \
     if (rl <= 4)                                                                                                       \
@@ -1824,19 +1811,18 @@ static int bond_z_launch(const double* G, const double* R, const double* v, doub
 }
 
 int ttk_bond_z_f64(const double* G, const double* R, const double* v, double* z, int64_t S, int rl, int p, int rr, int ca, int cb,
-                   int g_sample_major, void* stream) {
+                   void* stream) {
   if (!G || !R || !v || !z || !bond_fits(S, 1, rl, p, rr, ca, cb)) return TTK_EINVAL;
-  return bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, g_sample_major, (hipStream_t)stream);
+  return bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, (hipStream_t)stream);
 }
 
 int ttk_bond_jv_f64(const double* L, const double* G, const double* R, const double* v, double* u, int64_t S, int C, int rl,
-                    int p, int rr, int ca, int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes,
-                    void* stream) {
+                    int p, int rr, int ca, int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
   if (!L || !G || !R || !v || !u || !ws || !bond_fits(S, C, rl, p, rr, ca, cb)) return TTK_EINVAL;
   if (ws_bytes < ttk_bond_jv_ws_bytes(S, rl, ca)) return TTK_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* z = (double*)ws;
-  int rc = bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, g_sample_major, st);
+  int rc = bond_z_launch(G, R, v, z, S, rl, p, rr, ca, cb, st);
   if (rc != TTK_OK) return rc;
   const int64_t nu = S * C;
   hipLaunchKernelGGL(bond_u_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, L, (const double*)z, u, S, C, rl, ca,
@@ -1867,10 +1853,8 @@ int64_t ttk_bond_rhs_ws_bytes(int64_t S, int rl, int p, int rr) {
 }
 
 int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double* b, int64_t S, int rl, int p, int rr, int ca,
-                     int cb, int g_sample_major, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+                     int cb, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
   if (!GL || !G || !R || !b || !ws || !bond_fits(S, 1, rl, p, rr, ca, cb)) return TTK_EINVAL;
-  int64_t gsa, gsb, gss;
-  bond_g_strides(g_sample_major, S, p, ca, cb, &gsa, &gsb, &gss);
   if (ws_bytes < ttk_bond_rhs_ws_bytes(S, rl, p, rr)) return TTK_EWORKSPACE;
   const int64_t nslabs = bond_rhs_slabs(S);
   const int64_t slab = (S + nslabs - 1) / nslabs;
@@ -1881,7 +1865,7 @@ int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double*
   const int nr = (rr + 8 / ptw - 1) / (8 / ptw);                    // right-bond indices per wave
 #define BOND_RHS(NR_)                                                                                                  \
   hipLaunchKernelGGL(bond_rhs_kernel<NR_>, dim3((unsigned)used), dim3(512), 0, st, GL, G, R, partial, S, rl, p, rr, ca, cb, \
-                     slab, ptw, gsa, gsb, gss)
+                     slab, ptw)
   switch (nr) {
     case 1: BOND_RHS(1); break;
     case 2: BOND_RHS(2); break;

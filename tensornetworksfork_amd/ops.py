@@ -737,36 +737,29 @@ def filter_rhs(L, Z, g):
 _bond_ws = {}
 
 
-def _bond_dims(L, G, R, sample_major):
+def _bond_dims(L, G, R):
     ca, S, C, rl = L.shape
     cb, rr = R.shape[0], R.shape[2]
     p = G.shape[3]
-    want = (S, ca, cb, p) if sample_major else (ca, cb, S, p)
+    want = (ca, cb, S, p)
     return ca, cb, S, C, rl, p, rr, want
 
 
-def bond_supported(L, G, R, sample_major=False):
-    """True when the conv-bond kernels take the stacked factors L (ca,S,C,rl), G (ca,cb,S,p) [or (S,ca,cb,p) with
-    sample_major], R (cb,S,rr) of a column between two convolution bonds: contiguous float64 device tensors, small
-    bonds, few channels."""
+def bond_supported(L, G, R):
+    """True when the conv-bond kernels take the stacked factors L (ca,S,C,rl), G (ca,cb,S,p), R (cb,S,rr) of a column
+    between two convolution bonds: contiguous float64 device tensors, small bonds, few channels."""
     if not (L.is_cuda and L.dtype == F64 and G.dtype == F64 and R.dtype == F64):
         return False
     if not (L.is_contiguous() and G.is_contiguous() and R.is_contiguous()) or G.dim() != 4:
         return False
-    ca, cb, S, C, rl, p, rr, want = _bond_dims(L, G, R, sample_major)
+    ca, cb, S, C, rl, p, rr, want = _bond_dims(L, G, R)
     return S > 0 and tuple(G.shape) == want and bool(_lib.lib().ttk_bond_ok(S, C, rl, p, rr, ca, cb))
 
 
-def bond_sample_major(G):
-    """(ca,cb,S,p) -> (S,ca,cb,p) copy: the ca cb feature rows of a sample side by side (the layout the conv-bond
-    kernels read fastest: the 16 samples of a wave are then one contiguous range)."""
-    return G.permute(2, 0, 1, 3).contiguous()
-
-
-def bond_jv(L, G, R, v, out=None, sample_major=False):
+def bond_jv(L, G, R, v, out=None):
     """u (S,C) = sum_{a,b} L_a . (G_ab (x) R_b) . v for the ca cb Khatri-Rao terms of a column between two
     convolution bonds, in one launch; with `out` given the result is added to it."""
-    ca, cb, S, C, rl, p, rr, want = _bond_dims(L, G, R, sample_major)
+    ca, cb, S, C, rl, p, rr, want = _bond_dims(L, G, R)
     acc = out is not None
     u = out if acc else torch.empty((S, C), dtype=F64, device=L.device)
     nbytes = int(_lib.lib().ttk_bond_jv_ws_bytes(S, rl, ca))
@@ -778,12 +771,12 @@ def bond_jv(L, G, R, v, out=None, sample_major=False):
         ws = _bond_ws[key] = torch.empty((nbytes + 7) // 8, dtype=F64, device=L.device)
     rc = _lib.lib().ttk_bond_jv_f64(_chk(L, "L"), _chk(G, "G", want), _chk(R, "R", (cb, S, rr)),
                                     _chk(v, "v", (rl, p, rr)), _chk(u, "u", (S, C)), S, C, rl, p, rr, ca, cb,
-                                    int(sample_major), int(acc), ws.data_ptr(), nbytes, _stream(L))
+                                    int(acc), ws.data_ptr(), nbytes, _stream(L))
     _lib.check(rc, "ttk_bond_jv")
     return u
 
 
-def _bond_rhs_gl(GL, G, R, dims, out, sample_major):
+def _bond_rhs_gl(GL, G, R, dims, out):
     ca, cb, S, C, rl, p, rr, want = dims
     nbytes = int(_lib.lib().ttk_bond_rhs_ws_bytes(S, rl, p, rr))
     key = (GL.device, nbytes)
@@ -796,37 +789,37 @@ def _bond_rhs_gl(GL, G, R, dims, out, sample_major):
     acc = out is not None
     b = out if acc else torch.empty((rl, p, rr), dtype=F64, device=GL.device)
     rc = _lib.lib().ttk_bond_rhs_f64(GL.data_ptr(), _chk(G, "G", want), _chk(R, "R", (cb, S, rr)),
-                                     _chk(b, "b", (rl, p, rr)), S, rl, p, rr, ca, cb, int(sample_major), int(acc),
+                                     _chk(b, "b", (rl, p, rr)), S, rl, p, rr, ca, cb, int(acc),
                                      ws.data_ptr(), nbytes, _stream(GL))
     _lib.check(rc, "ttk_bond_rhs")
     return b
 
 
-def bond_rhs(L, G, R, g, out=None, sample_major=False):
+def bond_rhs(L, G, R, g, out=None):
     """b (rl,p,rr) = sum_s sum_{a,b} (g . L_a)[s,l] G_ab[s,p] R_b[s,r]: J^T g of a column between two convolution
     bonds (one launch for g . L_a, one for the sum over samples and terms, one to add the slab partials)."""
-    dims = _bond_dims(L, G, R, sample_major)
+    dims = _bond_dims(L, G, R)
     ca, cb, S, C, rl, p, rr, want = dims
     GL = torch.empty((ca, S, rl), dtype=F64, device=L.device)
     rc = _lib.lib().ttk_bond_gl_f64(_chk(g, "g", (S, C)), _chk(L, "L"), GL.data_ptr(), S, C, rl, ca, _stream(L))
     _lib.check(rc, "ttk_bond_gl")
-    return _bond_rhs_gl(GL, G, R, dims, out, sample_major)
+    return _bond_rhs_gl(GL, G, R, dims, out)
 
 
-def bond_matvec(L, G, R, H, v, sample_major=False):
+def bond_matvec(L, G, R, H, v):
     """q (rl,p,rr) = J^T H J v of a column between two convolution bonds: the first half down to the left bond (z), the
     left environments and the Hessian in one kernel (g . L of the Hessian-weighted prediction), the second half."""
-    dims = _bond_dims(L, G, R, sample_major)
+    dims = _bond_dims(L, G, R)
     ca, cb, S, C, rl, p, rr, want = dims
     z = torch.empty((ca, S, rl), dtype=F64, device=L.device)
     rc = _lib.lib().ttk_bond_z_f64(_chk(G, "G", want), _chk(R, "R", (cb, S, rr)), _chk(v, "v", (rl, p, rr)), z.data_ptr(),
-                                   S, rl, p, rr, ca, cb, int(sample_major), _stream(L))
+                                   S, rl, p, rr, ca, cb, _stream(L))
     _lib.check(rc, "ttk_bond_z")
     GL = torch.empty((ca, S, rl), dtype=F64, device=L.device)
     rc = _lib.lib().ttk_bond_lhl_f64(_chk(L, "L"), _chk(H, "H", (S, C, C)), z.data_ptr(), GL.data_ptr(), S, C, rl, ca,
                                      _stream(L))
     _lib.check(rc, "ttk_bond_lhl")
-    return _bond_rhs_gl(GL, G, R, dims, None, sample_major)
+    return _bond_rhs_gl(GL, G, R, dims, None)
 
 
 def conv_feature(X, Fc):

@@ -253,7 +253,7 @@ def bond_rhs(L, G, R, g, out=None):
     return b if out is None else out.add_(b)
 
 
-def bond_matvec(L, G, R, H, v, sample_major=False):
+def bond_matvec(L, G, R, H, v):
     u = bond_jv(L, G, R, v)
     return bond_rhs(L, G, R, torch.einsum('scd,sc->sd', H, u))
 

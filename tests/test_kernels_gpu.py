@@ -950,10 +950,6 @@ def test_conv_bond_kernels_match_einsum(S, C, rl, p, rr, ca, cb):
     H = (Hh + Hh.transpose(1, 2)).contiguous()
     q_ref = torch.einsum('sc,ascl,absp,bsr->lpr', torch.einsum('scd,sc->sd', H, u_ref), L, Gf, R)
     assert G.rel_err(ops.bond_matvec(L, Gf, R, H, v), q_ref) < 1e-12
-    Gs = ops.bond_sample_major(Gf)                            # the same sums from the sample-major layout of G
-    assert ops.bond_supported(L, Gs, R, sample_major=True)
-    assert torch.equal(ops.bond_jv(L, Gs, R, v, sample_major=True), u)
-    assert torch.equal(ops.bond_rhs(L, Gs, R, g, sample_major=True), b)
     assert not ops.bond_supported(mk(2, 8, 1, 17), mk(2, 2, 8, 5), mk(2, 8, 3))       # left bond beyond one tile
 
 

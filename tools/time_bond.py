@@ -37,17 +37,13 @@ if "filter" in which:
     timeit("filter_matvec n=17 ca=4", lambda: ops.filter_matvec(L, Z1, H, v1))
 if "jv" in which or "rhs" in which:
     G, R, v, gg = mk(ca, cb, S, p), mk(cb, S, rr), mk(rl, p, rr), mk(S, C)
-    Gs = ops.bond_sample_major(G)
-    timeit("sample-major copy of G", lambda: ops.bond_sample_major(G))
     if "jv" in which:
         timeit("bond_jv ca=cb=4", lambda: ops.bond_jv(L, G, R, v))
-        timeit("bond_jv sample-major", lambda: ops.bond_jv(L, Gs, R, v, sample_major=True))
     if "jv" in which and "rhs" in which:
         Hm = mk(S, C, C)
         timeit("bond_matvec ca=cb=4", lambda: ops.bond_matvec(L, G, R, Hm, v))
     if "rhs" in which:
         timeit("bond_rhs ca=cb=4", lambda: ops.bond_rhs(L, G, R, gg))
-        timeit("bond_rhs sample-major", lambda: ops.bond_rhs(L, Gs, R, gg, sample_major=True))
 if "patch" in which:
     U, X = mk(S, rl, p), mk(S, p, px)
     Zt = torch.empty((S, rl, 1, px, cb), dtype=torch.float64, device=dev)
