@@ -863,19 +863,31 @@ __global__ __launch_bounds__(512, sizeof(TC) == 4 && PTC <= 8 ? 4 : 2) void rhs_
   }
 }
 
-// out[i] (+)= sum over the slabs of partial[slab][i], slabs added in fixed order
-__global__ __launch_bounds__(256) void dense_reduce_slabs_kernel(const double* __restrict__ partial, int nslabs, int64_t n,
-                                                                  double* __restrict__ out, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double a0 = 0.0, a1 = 0.0;
-  int k = 0;
-  for (; k + 1 < nslabs; k += 2) {
-    a0 += partial[(int64_t)k * n + i];
-    a1 += partial[(int64_t)(k + 1) * n + i];
+// out[i] (+)= sum over the slabs of partial[slab][i] for many slabs and few outputs: 16 outputs x 16 slab groups per
+// workgroup, every thread's loads independent and in flight together, the 16 group sums added in fixed order
+__global__ __launch_bounds__(256) void dense_reduce_wide_kernel(const double* __restrict__ partial, int nslabs, int64_t n,
+                                                                double* __restrict__ out, int accumulate) {
+  __shared__ double part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
+  const int64_t src = idx < n ? idx : n - 1;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = g;
+  for (; k + 48 < nslabs; k += 64) {
+    a0 += partial[(int64_t)k * n + src];
+    a1 += partial[(int64_t)(k + 16) * n + src];
+    a2 += partial[(int64_t)(k + 32) * n + src];
+    a3 += partial[(int64_t)(k + 48) * n + src];
   }
-  if (k < nslabs) a0 += partial[(int64_t)k * n + i];
-  out[i] = (accumulate ? out[i] : 0.0) + (a0 + a1);
+  for (; k < nslabs; k += 16) a0 += partial[(int64_t)k * n + src];
+  part[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && idx < n) {
+    double acc = accumulate ? out[idx] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += part[q][o];
+    out[idx] = acc;
+  }
 }
 
 struct RhsFeatDims {
@@ -1081,7 +1093,7 @@ static int rhs_feature_launch(const double* GL, const double* X, const double* R
   int rc = dense_status();
   if (rc != TTK_OK) return rc;
   const int64_t D = (int64_t)rl * p * rr;
-  hipLaunchKernelGGL(dense_reduce_slabs_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const double*)partial,
+  hipLaunchKernelGGL(dense_reduce_wide_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, st, (const double*)partial,
                      d.nslabs, D, b, accumulate);
   return dense_status();
 }
@@ -1343,33 +1355,6 @@ __global__ __launch_bounds__(512, 2) void bond_rhs_kernel(const double* __restri
         if (po < p) out[((int64_t)li * p + po) * rr + r0c + j] = acc[j][t];
       }
     }
-  }
-}
-
-// out[i] (+)= sum over the slabs of partial[slab][i] for many slabs and few outputs: 16 outputs x 16 slab groups per
-// workgroup, every thread's loads independent and in flight together, the 16 group sums added in fixed order
-__global__ __launch_bounds__(256) void dense_reduce_wide_kernel(const double* __restrict__ partial, int nslabs, int64_t n,
-                                                                double* __restrict__ out, int accumulate) {
-  __shared__ double part[16][17];
-  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int64_t idx = (int64_t)blockIdx.x * 16 + o;
-  const int64_t src = idx < n ? idx : n - 1;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = g;
-  for (; k + 48 < nslabs; k += 64) {
-    a0 += partial[(int64_t)k * n + src];
-    a1 += partial[(int64_t)(k + 16) * n + src];
-    a2 += partial[(int64_t)(k + 32) * n + src];
-    a3 += partial[(int64_t)(k + 48) * n + src];
-  }
-  for (; k < nslabs; k += 16) a0 += partial[(int64_t)k * n + src];
-  part[g][o] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (g == 0 && idx < n) {
-    double acc = accumulate ? out[idx] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc += part[q][o];
-    out[idx] = acc;
   }
 }
 
