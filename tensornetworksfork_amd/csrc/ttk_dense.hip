@@ -1416,7 +1416,7 @@ template <int MODE, int NKT>   // NKT: 16-column tiles of q a wave keeps (n <= 1
 __global__ __launch_bounds__(256) void filter_hjv_kernel(const double* __restrict__ Lenv, const double* __restrict__ Z,
                                                          const double* __restrict__ H, const double* __restrict__ x,
                                                          double* __restrict__ out, int64_t S, int C, int rl, int n, int ca,
-                                                         int nwaves) {
+                                                         int nwaves, int wide_ok) {
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, kq = lane >> 4;
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(256) void filter_hjv_kernel(const double* __restric
   if (wave < nwaves) {
     // A sample's factors go straight to the wave's LDS images (LDS-DMA: no staging registers, all loads of the
     // sample in flight together): one memory round trip per sample, hidden by the other waves of the CU.
-    const bool wide = ((zn | ncl | (hlds ? C * C : 0)) & 1) == 0;   // every block a whole number of 16-byte units
+    const bool wide = wide_ok != 0;   // every block a whole number of 16-byte units at a 16-byte aligned address
     for (int64_t s = gw; s < S; s += stride) {
       wave_dma_copy(Z + s * (int64_t)zn, zn, Zs, lane, wide);
       for (int a = 0; a < ca; ++a) wave_dma_copy(Lenv + ((int64_t)a * S + s) * ncl, ncl, Ls + a * lreg, lane, wide);
@@ -1711,9 +1711,15 @@ static int filter_launch(int mode, const double* L, const double* Z, const doubl
   if (mode != 1 && (!ws || ws_bytes < ttk_filter_ws_bytes(S, C, rl, n, ca))) return TTK_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
+  // 16-byte DMA units need even block lengths and 16-byte aligned bases (the C ABI promises 8)
+  const bool hl = mode == 0 && C <= 16;
+  const int wide = ((rl * n) % 2 == 0 && (C * rl) % 2 == 0 && (!hl || (C * C) % 2 == 0) &&
+                    (((uintptr_t)L | (uintptr_t)Z | (hl ? (uintptr_t)H : 0)) & 15) == 0)
+                       ? 1
+                       : 0;
 #define FILTER_GO(MODE_, NKT_, OUT_)                                                                                  \
   hipLaunchKernelGGL((filter_hjv_kernel<MODE_, NKT_>), dim3(d.grid), dim3(256), d.lds, st, L, Z, H, x, OUT_, S, C, rl, n, ca, \
-                     d.nwaves)
+                     d.nwaves, wide)
 #define FILTER_NKT(MODE_)                                                                                              \
   {                                                                                                                    \
     const int nkt = (n + 15) / 16;                                                                                     \

@@ -982,6 +982,12 @@ def test_factored_filter_operator_matches_rows(S, C, rl, n, ca):
     q = ops.filter_matvec(L, Z, H, v)
     assert G.rel_err(q, q_ref) < 1e-12
     assert torch.equal(q, ops.filter_matvec(L, Z, H, v))          # fixed order of the partial sums
+    # factors that start 8 bytes off a 16-byte boundary (allowed by the C ABI) go by 4-byte DMA units: same numbers
+    off = lambda t: torch.cat([t.new_zeros(1), t.reshape(-1)])[1:].reshape(t.shape)   # noqa: E731
+    Lo, Zo, Ho = off(L), off(Z), off(H)
+    assert Lo.data_ptr() % 16 == 8 and Zo.is_contiguous()
+    assert torch.equal(ops.filter_matvec(Lo, Zo, Ho, v), q)
+    assert torch.equal(ops.filter_rhs(Lo, Zo, g), b)
     assert not ops.filter_supported(mk(4, 8, 2, 17), mk(8, 17, 5))              # ca rl beyond one wave
 
 
