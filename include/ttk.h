@@ -264,6 +264,13 @@ int ttk_minres_update_ws_f64(double* y, double* r1, double* r2, double* v, doubl
                              int64_t D, void* ws, int64_t ws_bytes, void* stream);
 int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur, double* v_next, double* alphas,
                            double* betas, int j, int64_t D, double tol, double* stop, void* stream);
+/* Iterations j_first .. j_first + count - 1 of the Lanczos recurrence on the operator of one Khatri-Rao term with one
+ * output (the extents ttk_matvec_fused_f64 takes), queued by one call: per iteration the fused product of row j - 1 of
+ * the basis V (rows ldv doubles apart) into w (D doubles of scratch), then ttk_lanczos_update_f64 writing row j.  No
+ * host work between the launches of an iteration (tensor/network.py:805-814 without the interpreter in the loop). */
+int ttk_lanczos_fused_block_f64(const double* L, const double* X, const double* R, const double* H, double* V, int64_t ldv,
+                                double* alphas, double* betas, double* stop, int j_first, int count, double tol, double* w,
+                                int64_t S, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream);
 int64_t ttk_lanczos_finish_ws_bytes(int m_cap);
 int ttk_lanczos_finish_f64(const double* V, int64_t ldv, const double* alphas, const double* betas, const double* stop,
                            int m_run, int m_cap, const double* x0, double* x, int64_t D, void* ws, int64_t ws_bytes,

@@ -95,6 +95,8 @@ SIGNATURES = {
     "ttk_dense_scale_f64": (_int, [_c_dp, _int, _c_dp, _c_dp]),
     "ttk_chol_prepare_dense_f64": (_int, [_c_dp, _int, _c_dp, _dbl, _c_dp, _c_dp, _c_dp, _c_dp]),
     "ttk_lanczos_update_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _int, _i64, _dbl, _c_dp, _c_dp]),
+    "ttk_lanczos_fused_block_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _int, _int, _dbl, _c_dp,
+                                           _i64, _int, _int, _int, _c_dp, _i64, _c_dp]),
     "ttk_lanczos_finish_ws_bytes": (_i64, [_int]),
     "ttk_lanczos_finish_f64": (_int, [_c_dp, _i64, _c_dp, _c_dp, _c_dp, _int, _int, _c_dp, _c_dp, _i64, _c_dp, _i64, _c_dp]),
     "ttk_rows_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _c_dp]),

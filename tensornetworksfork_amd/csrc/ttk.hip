@@ -4440,7 +4440,7 @@ static double* static_scratch_ptr() {
 }
 
 // Event pairs around the Gram kernel (diagnostic; armed by ttk_gram_timing).
-static const int kTimingPool = 512;
+static const int kTimingPool = 2048;
 static hipEvent_t g_ev_start[kTimingPool], g_ev_stop[kTimingPool];
 static bool g_ev_created = false, g_ev_armed = false;
 static int g_ev_count = 0;
@@ -5148,6 +5148,22 @@ int ttk_lanczos_update_f64(double* w, const double* v_prev, const double* v_cur,
     hipLaunchKernelGGL(lanczos_wide_kernel<2>, dim3(LZW_WG), dim3(256), 0, st, w, v_prev, v_cur, v_next, betas, j, D, cstop);
   }
   return ttk_launch_status();
+}
+
+int ttk_lanczos_fused_block_f64(const double* L, const double* X, const double* R, const double* H, double* V, int64_t ldv,
+                                double* alphas, double* betas, double* stop, int j_first, int count, double tol, double* w,
+                                int64_t S, int rl, int p, int rr, void* ws, int64_t ws_bytes, void* stream) {
+  if (!V || !alphas || !betas || !stop || !w || j_first < 1 || count < 0) return TTK_EINVAL;
+  const int64_t D = (int64_t)rl * p * rr;
+  if (ldv < D) return TTK_EINVAL;
+  for (int j = j_first; j < j_first + count; ++j) {
+    int rc = ttk_matvec_fused_f64(L, X, R, H, V + (int64_t)(j - 1) * ldv, w, S, rl, p, rr, ws, ws_bytes, stream);
+    if (rc != TTK_OK) return rc;
+    rc = ttk_lanczos_update_f64(w, j > 1 ? V + (int64_t)(j - 2) * ldv : nullptr, V + (int64_t)(j - 1) * ldv, V + (int64_t)j * ldv,
+                                alphas, betas, j, D, tol, stop, stream);
+    if (rc != TTK_OK) return rc;
+  }
+  return TTK_OK;
 }
 
 int64_t ttk_lanczos_finish_ws_bytes(int m_cap) {

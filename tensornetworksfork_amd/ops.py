@@ -337,6 +337,29 @@ class CGFused:
         _lib.check(rc, "ttk_cg_fused_iter_f64")
 
 
+class LanczosFused:
+    """The Lanczos recurrence on the operator of one Khatri-Rao term (extents of the one-pass product kernel): a block
+    of iterations is queued by ONE library call, three launches per iteration and no interpreter work between them."""
+
+    def __init__(self, L, X, R, H):
+        S, C, rl = L.shape
+        self.dims = (S, rl, X.shape[1], R.shape[1])
+        self.ptrs = (_chk(L, "L"), _chk(X, "X", (S, X.shape[1])), _chk(R, "R", (S, R.shape[1])), _chk(H, "H", (S, 1, 1)))
+        self.keep = (L, X, R, H)
+        self.ws, self.nbytes = _mvf_workspace(S, rl, X.shape[1], R.shape[1], L.device)
+        self.w = torch.empty(rl * X.shape[1] * R.shape[1], dtype=F64, device=L.device)
+
+    def block(self, V, alphas, betas, stop, j_first, count, tol):
+        """Iterations j_first .. j_first + count - 1: row j of V from rows j - 1 and j - 2."""
+        S, rl, p, rr = self.dims
+        if V.stride(1) != 1 or V.dtype != F64 or not V.is_cuda or V.shape[1] != rl * p * rr or V.shape[0] < j_first + count:
+            raise _lib.TTKError("LanczosFused.block: expected a float64 device basis (rows, D) with contiguous rows")
+        rc = _lib.lib().ttk_lanczos_fused_block_f64(*self.ptrs, V.data_ptr(), V.stride(0), alphas.data_ptr(), betas.data_ptr(),
+                                                    stop.data_ptr(), int(j_first), int(count), float(tol), self.w.data_ptr(),
+                                                    S, rl, p, rr, self.ws.data_ptr(), self.nbytes, _stream(V))
+        _lib.check(rc, "ttk_lanczos_fused_block_f64")
+
+
 class CGPlan:
     """The fused CG loop of one problem shape with buffers of its own, so that a block of iterations can be
     captured as a HIP graph ONCE and replayed for every core update of that shape (the operands of an update
@@ -499,7 +522,7 @@ def gram_timing(enable):
     _lib.check(_lib.lib().ttk_gram_timing(int(enable)), "ttk_gram_timing")
 
 
-def gram_timing_read(max_n=512):
+def gram_timing_read(max_n=2048):
     """Durations (ms) of the Gram kernel launches recorded since the last read."""
     import ctypes
     buf = (ctypes.c_double * max_n)()

@@ -322,6 +322,16 @@ class LocalProblem:
             return None
         return ops.CGFused(L.contiguous(), X.contiguous(), R.contiguous(), H)
 
+    def lanczos_fused(self, H):
+        """ops.LanczosFused for this problem's operator under the same conditions as cg_fused, else None."""
+        if self.terms is None or len(self.terms) != 1:
+            return None
+        L, X, R = self.terms[0]
+        if not (L.is_cuda and L.dtype == F64 and tuple(H.shape) == (L.shape[0], 1, 1) and
+                ops.matvec_fused_supported(L.shape[0], L.shape[1], L.shape[2], X.shape[1], R.shape[1])):
+            return None
+        return ops.LanczosFused(L.contiguous(), X.contiguous(), R.contiguous(), H.contiguous())
+
     def slice(self, lo, hi):
         """The same problem restricted to samples [lo, hi) (first-axis views, no copies)."""
         if self.J is not None:

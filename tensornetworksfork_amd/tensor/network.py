@@ -809,7 +809,8 @@ class TensorNetwork:
                 x0 = self._engine.to_canon(node, x0n.to(device)).reshape(lp.shape)
                 if d.sharded:
                     self._shard.broadcast_(x0)
-                step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol, lockstep=d.sharded)
+                fused = None if d.sharded else lp.lanczos_fused(H)   # (a sharded product needs an all-reduce in between)
+                step = lanczos_solve(self._matvec_fn(d, lp, H), -b, x0, max_iter, tol, lockstep=d.sharded, fused=fused)
                 node.update_node(lp.back(step), lr=lr)
                 if block_callback is not None:
                     block_callback(NS, node)

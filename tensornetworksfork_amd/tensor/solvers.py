@@ -15,7 +15,7 @@ def _cholesky_solve(A_f, rhs):
     return torch.cholesky_solve(rhs.unsqueeze(-1), Lc).squeeze(-1)
 
 
-def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False):
+def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False, fused=None):
     """Lanczos-Galerkin without re-orthogonalisation (tensor/network.py:796-824).
     Each iteration is the operator product plus one fused vector kernel that writes the next row of the
     basis; alpha / beta stay on the device.  The reference's exit (beta < tol) is taken inside that
@@ -24,7 +24,8 @@ def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False):
     `check_every` iterations it starts a copy of it to pinned memory and reads the copy started one
     period earlier, which has long arrived - no wait.  `lockstep` (sample-sharded runs: every rank
     must queue the same number of products, each holds an all-reduce) reads the record itself at
-    those points instead.  The tridiagonal solve and x0 + V y run on the device (ops.lanczos_finish)."""
+    those points instead.  The tridiagonal solve and x0 + V y run on the device (ops.lanczos_finish).
+    `fused` (ops.LanczosFused): the iterations between two looks at the record are queued by one library call."""
     shape = x0.shape
     D = x0.numel()
     dev = x0.device
@@ -40,11 +41,17 @@ def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False):
     torch.div(r0, beta1, out=V[0])
     m = 0
     in_flight = None
-    for j in range(1, max_iter + 1):
-        w = matvec(V[j - 1].reshape(shape)).reshape(-1)
-        if not w.is_contiguous():
-            w = w.contiguous()
-        ops.lanczos_update(w, V[j - 2] if j > 1 else None, V[j - 1], V[j], alphas, betas, j, tol, stop)
+    j = 1
+    while j <= max_iter:
+        if fused is not None and x0.dtype == torch.float64:
+            count = min(check_every - (j - 1) % check_every, max_iter - j + 1)
+            fused.block(V, alphas, betas, stop, j, count, tol)
+            j += count - 1
+        else:
+            w = matvec(V[j - 1].reshape(shape)).reshape(-1)
+            if not w.is_contiguous():
+                w = w.contiguous()
+            ops.lanczos_update(w, V[j - 2] if j > 1 else None, V[j - 1], V[j], alphas, betas, j, tol, stop)
         m = j
         if j % check_every == 0 and j < max_iter:
             if lockstep or not dev.type == 'cuda':
@@ -61,6 +68,7 @@ def lanczos_solve(matvec, b, x0, max_iter, tol, check_every=8, lockstep=False):
                 ready = torch.cuda.Event()
                 ready.record()
                 in_flight = (host, ready)
+        j += 1
     return ops.lanczos_finish(V, alphas, betas, stop, m, x0).reshape(shape)
 
 

@@ -1012,3 +1012,25 @@ def test_patch_contract_all_channels_in_one_pass(S, C, P, px, nb, dt):
     assert torch.equal(Z1.reshape(S, C, px, nb), Z)
     assert ops.patch_contract_multi(torch.zeros(4, 2, 16, 100, dtype=torch.float64, device=dev),
                                     torch.zeros(2, 100, 49, dtype=torch.float64, device=dev)) is None   # beyond the LDS
+
+
+@gpu
+@pytest.mark.parametrize("S,rl,p,max_iter", [(3000, 32, 6, 21), (700, 16, 4, 8), (260, 16, 8, 5)])
+def test_lanczos_blocks_queued_by_one_call_equal_single_iterations(S, rl, p, max_iter):
+    """The Lanczos solve with its iterations queued in blocks by one library call (ops.LanczosFused) against the same
+    solve with one product call and one vector-kernel call per iteration: the same kernels in the same order, bit-equal."""
+    from tensornetworksfork_amd import ops
+    from tensornetworksfork_amd.tensor.solvers import lanczos_solve
+    dev = _dev()
+    L, X, R = _rand((S, 1, rl), 1).to(dev), _rand((S, p), 2).to(dev), _rand((S, rl), 3).to(dev)
+    H = (_rand((S, 1, 1), 4).abs() + 0.5).to(dev)
+    assert ops.matvec_fused_supported(S, 1, rl, p, rl)
+    b, x0 = _rand((rl, p, rl), 5).to(dev), _rand((rl, p, rl), 6).to(dev)
+    mv = lambda v: ops.matvec(L, X, R, H, v.reshape(rl, p, rl).contiguous())   # noqa: E731
+    plain = lanczos_solve(mv, b, x0, max_iter, 1e-9)
+    fused = lanczos_solve(mv, b, x0, max_iter, 1e-9, fused=ops.LanczosFused(L, X, R, H))
+    assert torch.equal(plain, fused)
+    # and it solves the Galerkin system: the residual is orthogonal to the start residual
+    r0 = b - mv(x0)
+    res = b - mv(fused)
+    assert abs(float((res * r0).sum())) <= 1e-8 * float(r0.norm()) * float(res.norm() + r0.norm())
