@@ -924,7 +924,8 @@ def test_feature_maps_on_device():
 
 @gpu
 @pytest.mark.parametrize("S,C,rl,p,rr,ca,cb", [(1000, 9, 10, 50, 10, 4, 4), (77, 1, 3, 17, 5, 2, 3), (64, 10, 16, 31, 16, 1, 4),
-                                                (129, 2, 1, 7, 13, 4, 1), (5, 3, 9, 128, 4, 3, 2), (4100, 1, 10, 50, 1, 4, 2)])
+                                                (129, 2, 1, 7, 13, 4, 1), (5, 3, 9, 128, 4, 3, 2), (4100, 1, 10, 50, 1, 4, 2),
+                                                (100, 2, 14, 20, 6, 4, 2), (333, 12, 7, 16, 9, 2, 4)])
 def test_conv_bond_kernels_match_einsum(S, C, rl, p, rr, ca, cb):
     """The one-launch halves of the operator of a column between convolution bonds against the plain sum over the
     ca cb Khatri-Rao terms (float64 einsum on the device), plain and accumulating."""
