@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 tag=$1; shift
 rm -rf $OUT/pmcb_$tag
-timeout -s KILL 400 rocprofv3 --pmc "$@" -d $OUT/pmcb_$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmcb_$tag.log 2>&1 || { echo "pmc $tag failed"; tail -5 $OUT/pmcb_$tag.log; exit 1; }
+timeout -s KILL 400 rocprofv3 --pmc "$@" -d $OUT/pmcb_$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${TTK_PMC_BENCH_FLAGS:-} > $OUT/pmcb_$tag.log 2>&1 || { echo "pmc $tag failed"; tail -5 $OUT/pmcb_$tag.log; exit 1; }
 f=$(find $OUT/pmcb_$tag -name "*counter_collection.csv" | head -1)
 python3 - "$f" "$OUT/r03_pmc_$tag.csv" <<'P'
 import csv, sys, collections
