@@ -140,7 +140,8 @@ def _recorded_traffic(name):
 
 def _timed_kernel(which, fn):
     """Run fn() with HIP events armed around every launch of one kernel (ttk_gram_timing: 2 the fused
-    matrix-free product, 3 the features-first right-hand side, 4 the resident right-environment step);
+    matrix-free product, 3 the features-first right-hand side, 4 the resident right-environment step, 5 / 6 the
+    second / first half of the operator of a column between convolution bonds);
     returns the launch durations in ms."""
     from tensornetworksfork_amd import ops
     ops.gram_timing(which)
@@ -308,13 +309,23 @@ def conv_lanczos_variant(device, S, patches, pixels, bond, dtype, conv_bond, tol
     roofs = []
     try:
         tn.train_nodes = [mid]
-        for which, kernel in ((3, "rhs_feature_kernel"), (4, "env_right_resident_kernel")):
+        Sl = (S + world - 1) // world
+        if conv_bond > 0:
+            # a column between two convolution bonds (ca = cb = conv_bond): the two halves of its operator, fp64; FLOPs
+            # of the factorisations the kernels use: J^T: T_a = sum_b G_ab R_b, then sum_a T_a (x) GL_a; J: Y_b = v . R_b,
+            # then sum_{a,b,p} G_ab Y_b
+            ca = cb = conv_bond
+            kernels = ((5, "bond_rhs_kernel", 2.0 * Sl * ca * p * rr * (cb + rl)),
+                       (6, "bond_jv_kernel", 2.0 * Sl * cb * p * rl * (rr + ca)))
+        else:
+            kernels = ((3, "rhs_feature_kernel", 2.0 * Sl * rl * p * rr), (4, "env_right_resident_kernel", 2.0 * Sl * rl * p * rr))
+        for which, kernel, flops in kernels:
             torch.manual_seed(1)
             ms = _timed_kernel(which, lambda: tn.lanczos_swipe(x, y, bf, batch_size=512, num_swipes=1, max_iter=max_iter))
-            peak = FP32_MFMA_PEAK_TFLOPS if dtype == torch.float32 else FP64_MFMA_PEAK_TFLOPS
+            f32 = dtype == torch.float32 and conv_bond <= 0
+            peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
             if ms:
-                roofs.append(_mfma_roofline(kernel + ("<float>" if dtype == torch.float32 else "<double>"),
-                                            2.0 * ((S + world - 1) // world) * rl * p * rr, ms, peak))
+                roofs.append(_mfma_roofline(kernel + ("<float>" if f32 else "<double>"), flops, ms, peak))
     finally:
         tn.train_nodes = all_nodes
     iters = max_iter + 1      # products per node: the residual of the start vector + one per iteration

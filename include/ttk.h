@@ -102,7 +102,9 @@ int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, con
  * counterpart in the reference; used by bench.py for the roofline figure).
  * ttk_gram_timing(1) creates a pool of event pairs and arms recording around every
  * subsequent Gram kernel launch (ttk_gram_timing(2): around every launch of the fused
- * matrix-free product kernel instead); ttk_gram_timing(0) disarms.  ttk_gram_timing_read
+ * matrix-free product kernel instead; 3 / 4: the features-first right-hand side / the resident right-environment step
+ * of a site with many features; 5 / 6: the second / first half of the operator of a column between convolution
+ * bonds); ttk_gram_timing(0) disarms.  ttk_gram_timing_read
  * waits for the recorded pairs, writes up to `max` durations (milliseconds, launch
  * order) to ms_out (HOST pointer), clears the list and returns how many it wrote. */
 int ttk_gram_timing(int enable);

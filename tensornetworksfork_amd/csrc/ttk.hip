@@ -4470,7 +4470,7 @@ int ttk_gram_timing(int enable) {
     g_ev_created = true;
   }
   g_ev_armed = enable != 0;
-  g_ev_which = enable >= 1 && enable <= 5 ? enable : 1;
+  g_ev_which = enable >= 1 && enable <= 6 ? enable : 1;
   g_ev_count = 0;
   return TTK_OK;
 }

@@ -1777,6 +1777,7 @@ static int bond_z_launch(const double* G, const double* R, const double* v, doub
   const int ks = (rr + 3) / 4;
   const dim3 grid((unsigned)((S + 63) / 64));
   const size_t lds = (size_t)p * 4 * ks * rl * sizeof(double);
+  const bool timed = ttk_timing_begin(6, st);
 #define BOND_JV(CA_, RLT_)                                                                                             \
   hipLaunchKernelGGL((bond_jv_kernel<CA_, RLT_>), grid, dim3(256), lds, st, G, R, v, z, S, rl, p, rr, cb)
 #define BOND_JV_RL(CA_)                                                                                                \
@@ -1798,6 +1799,7 @@ static int bond_z_launch(const double* G, const double* R, const double* v, doub
   }
 #undef BOND_JV_RL
 #undef BOND_JV
+  if (timed) ttk_timing_end(st);
   return dense_status();
 }
 
@@ -1852,6 +1854,7 @@ int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double*
   const int64_t used = (S + slab - 1) / slab;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
+  const bool timed = ttk_timing_begin(5, st);
   const int ptw = p <= 16 ? 1 : p <= 32 ? 2 : p <= 64 ? 4 : 8;      // feature tiles (waves along p); 8 / ptw groups of r
   const int nr = (rr + 8 / ptw - 1) / (8 / ptw);                    // right-bond indices per wave
 #define BOND_RHS(NR_)                                                                                                  \
@@ -1869,6 +1872,7 @@ int ttk_bond_rhs_f64(const double* GL, const double* G, const double* R, double*
     default: BOND_RHS(16); break;
   }
 #undef BOND_RHS
+  if (timed) ttk_timing_end(st);
   int rc = dense_status();
   if (rc != TTK_OK) return rc;
   const int64_t D = (int64_t)rl * p * rr;
