@@ -829,6 +829,29 @@ def bond_rhs(L, G, R, g, out=None):
     return _bond_rhs_gl(GL, G, R, dims, out)
 
 
+def bond_z_supported(G, R, core):
+    """True when bond_z takes the stacked features G (ca,cb,S,p), right environments R (cb,S,rr) and a core (rl,p,rr)."""
+    if not (G.is_cuda and G.dtype == F64 and R.dtype == F64 and core.dtype == F64 and G.dim() == 4 and R.dim() == 3):
+        return False
+    if not (G.is_contiguous() and R.is_contiguous()):
+        return False
+    ca, cb, S, p = G.shape
+    rl, rr = core.shape[0], core.shape[2]
+    return S > 0 and tuple(R.shape) == (cb, S, rr) and bool(_lib.lib().ttk_bond_ok(S, 1, rl, p, rr, ca, cb))
+
+
+def bond_z(G, R, core):
+    """z (ca,S,rl), z_a[s,l] = sum_b sum_{p,r} core[l,p,r] G_ab[s,p] R_b[s,r]: the right-environment step through a
+    column between two convolution bonds for all left channels in one launch (also the first half of bond_matvec)."""
+    ca, cb, S, p = G.shape
+    rl, rr = core.shape[0], core.shape[2]
+    z = torch.empty((ca, S, rl), dtype=F64, device=G.device)
+    rc = _lib.lib().ttk_bond_z_f64(_chk(G, "G"), _chk(R, "R", (cb, S, rr)), _chk(core.contiguous(), "core", (rl, p, rr)),
+                                   z.data_ptr(), S, rl, p, rr, ca, cb, _stream(G))
+    _lib.check(rc, "ttk_bond_z")
+    return z
+
+
 def bond_matvec(L, G, R, H, v):
     """q (rl,p,rr) = J^T H J v of a column between two convolution bonds: the first half down to the left bond (z), the
     left environments and the Hessian in one kernel (g . L of the Hessian-weighted prediction), the second half."""

@@ -787,6 +787,10 @@ class ChainEngine(EngineBase):
             else:
                 Rn, G, core = self.right(d, k + 1), self.feats(d, k + 1), self.canonA(k + 1)
                 ca, cb = G.shape[0], G.shape[1]
+                if ca * cb > 1 and ops.bond_z_supported(G, Rn, core):
+                    # small bonds around a convolution bond: all ca cb terms in one launch
+                    d.R[k] = ops.bond_z(G, Rn, core)
+                    return d.R[k]
                 outs = []
                 for a in range(ca):
                     o = None

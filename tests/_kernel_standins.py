@@ -253,6 +253,15 @@ def bond_rhs(L, G, R, g, out=None):
     return b if out is None else out.add_(b)
 
 
+def bond_z_supported(G, R, core):
+    return G.dim() == 4 and G.is_contiguous() and R.is_contiguous() and core.shape[0] <= 16 and core.shape[2] <= 16 \
+        and G.shape[0] <= 4 and G.shape[1] <= 4 and G.shape[3] <= 128
+
+
+def bond_z(G, R, core):
+    return torch.einsum('lpr,absp,bsr->asl', core, G, R).contiguous()
+
+
 def bond_matvec(L, G, R, H, v):
     u = bond_jv(L, G, R, v)
     return bond_rhs(L, G, R, torch.einsum('scd,sc->sd', H, u))
@@ -364,7 +373,7 @@ def lanczos_finish(V, alphas, betas, stop, m_run, x0):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec patch_contract_multi lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec bond_z_supported bond_z patch_contract_multi lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
 
 
 def install(monkeypatch):
