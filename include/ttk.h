@@ -348,6 +348,11 @@ int ttk_env_right_dense_f64(const double* R, const double* X, const double* core
                             int rr, int accumulate, void* stream);
 int ttk_lcontract_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int accumulate,
                       void* stream);
+/* out[b][s,c,j] = sum_a sum_l L_a[s,c,l] T_ab[s,l,j]: second stage of the left-environment step through a column between
+ * two convolution bonds (tensor/layers.py:839-872: the sum over the left channel a), all right channels b in one launch.
+ * L (ca,S,C,rl), T (ca,nb,S,rl,n) = the row GEMM G_ab . core of every term, out (nb,S,C,n); ca C rl * 8 <= 48 KiB. */
+int ttk_lcontract_sum_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int ca, int nb,
+                          void* stream);
 /* The same with the (S, C, n) result rows inside a wider tensor: row (s, c) starts at out + s ostride_s + c ostride_c
  * (in doubles; ostride_c >= n, ostride_s >= C n), n contiguous.  The Jacobian rows J[s,c,a,(x,b)] of a conv filter
  * node between two convolution bonds (tensor/layers.py:839-872) are written in place, one call per left channel a. */

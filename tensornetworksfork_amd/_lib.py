@@ -66,6 +66,7 @@ SIGNATURES = {
     "ttk_gemm_rows_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_env_right_dense_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
     "ttk_lcontract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _c_dp]),
+    "ttk_lcontract_sum_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp]),
     "ttk_lcontract_strided_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),
     "ttk_patch_contract_f32": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _i64, _i64, _i64, _int, _c_dp]),

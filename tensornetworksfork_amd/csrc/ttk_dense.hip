@@ -538,6 +538,43 @@ __global__ __launch_bounds__(256) void lcontract_kernel(const double* __restrict
   }
 }
 
+// out[b][s,c,j] = sum_a sum_l L_a[s,c,l] T_ab[s,l,j]: the left-environment step through a column between convolution
+// bonds once its features are contracted (T_ab = G_ab . core for all terms as ONE row GEMM over the stacked features):
+// the sum over the left channels a stays in registers, one launch for all b (blockIdx.y) instead of one per term.
+// L (ca,S,C,rl), T (ca,nb,S,rl,n), out (nb,S,C,n).  Same work split as lcontract_kernel.
+__global__ __launch_bounds__(256) void lcontract_sum_kernel(const double* __restrict__ L, const double* __restrict__ T,
+                                                             double* __restrict__ out, int64_t S, int C, int rl, int n,
+                                                             int spb, int ca, int nb) {
+  extern __shared__ double Ls[];   // [ca][spb][C * rl]
+  const int64_t s0 = (int64_t)blockIdx.x * spb;
+  const int b = blockIdx.y;
+  const int ns = (int)min((int64_t)spb, S - s0);
+  const int CL = C * rl;
+  for (int a = 0; a < ca; ++a)
+    for (int k = threadIdx.x; k < ns * CL; k += 256) Ls[a * spb * CL + k] = L[((int64_t)a * S + s0) * CL + k];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < ns * n; idx += 256) {
+    const int sl = idx / n, j = idx - sl * n;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      double acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+      for (int a = 0; a < ca; ++a) {
+        const double* Lrow = Ls + (a * spb + sl) * CL;
+        const double* Ts = T + ((((int64_t)a * nb + b) * S + s0 + sl) * rl) * n + j;
+        for (int l = 0; l < rl; ++l) {
+          const double t = Ts[(int64_t)l * n];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] += Lrow[min(c0 + c, C - 1) * rl + l] * t;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c0 + c < C) out[(((int64_t)b * S + s0 + sl) * C + c0 + c) * n + j] = acc[c];
+    }
+  }
+}
+
 // J[s,c,x,b] (+)= sum_p Mv_b[s,c,p] X[s,p,x] for b < nb, written with sample stride jstride_s, row stride jstride_c,
 // column stride xstride and the nb results of a (c, x) side by side (the Jacobian rows of a conv filter node
 // C_k[a,x,b] sit at J[s,c,a,x,b]; with nb channels in one call the image rows are read once, not nb times).
@@ -1938,6 +1975,19 @@ int ttk_lcontract_strided_f64(const double* L, const double* T, double* out, int
   const size_t lds = (size_t)spb * C * rl * sizeof(double);
   hipLaunchKernelGGL(lcontract_kernel, dim3((unsigned)((S + spb - 1) / spb)), dim3(256), lds, (hipStream_t)stream, L, T, out,
                      S, C, rl, n, spb, accumulate, ostride_s, ostride_c);
+  return dense_status();
+}
+
+int ttk_lcontract_sum_f64(const double* L, const double* T, double* out, int64_t S, int C, int rl, int n, int ca, int nb,
+                          void* stream) {
+  if (!L || !T || !out || S < 1 || C < 1 || rl < 1 || n < 1 || ca < 1 || nb < 1 || nb > 65535) return TTK_EINVAL;
+  int spb = n >= 256 ? 1 : 256 / n;
+  const int fit = (int)(48 * 1024 / ((size_t)ca * C * rl * sizeof(double)));
+  if (fit < 1) return TTK_EINVAL;
+  if (spb > fit) spb = fit;
+  const size_t lds = (size_t)ca * spb * C * rl * sizeof(double);
+  hipLaunchKernelGGL(lcontract_sum_kernel, dim3((unsigned)((S + spb - 1) / spb), (unsigned)nb), dim3(256), lds,
+                     (hipStream_t)stream, L, T, out, S, C, rl, n, spb, ca, nb);
   return dense_status();
 }
 

@@ -911,6 +911,22 @@ def lcontract(L, T, out=None):
     return o
 
 
+def lcontract_sum(L, T):
+    """out (nb, S, C, n) = sum_a sum_l L[a,s,c,l] T[a,b,s,l,:]  for L (ca, S, C, rl), T (ca, nb, S, rl, n), or None when
+    the left environments of a sample do not fit the kernel's LDS."""
+    ca, S, C, rl = L.shape
+    nb, n = T.shape[1], T.shape[4]
+    if ca * C * rl * 8 > 48 * 1024 or nb > 65535:
+        return None
+    out = torch.empty((nb, S, C, n), dtype=F64, device=L.device)
+    if S == 0:
+        return out
+    rc = _lib.lib().ttk_lcontract_sum_f64(_chk(L, "L"), _chk(T, "T", (ca, nb, S, rl, n)), out.data_ptr(), S, C, rl, n, ca, nb,
+                                          _stream(L))
+    _lib.check(rc, "ttk_lcontract_sum_f64")
+    return out
+
+
 def lcontract_into(L, T, J, a):
     """J[s, c, a, :] = sum_l L[s,c,l] T[s,l,:]  for J (S, C, ca, n) contiguous: the rows of one left channel of a
     conv filter node's Jacobian, written in place."""

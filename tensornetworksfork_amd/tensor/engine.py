@@ -146,6 +146,9 @@ def _rhs_features_first(rl, p, rr):
     return passes >= 6
 
 
+BOND_LEFT_MAX_BYTES = 2 << 30     # largest stacked intermediate of the one-launch left step through a convolution bond
+
+
 class LocalProblem:
     """The normal equations of one train node for a bound data set.
 
@@ -765,6 +768,14 @@ class ChainEngine(EngineBase):
         ca, cb = G.shape[0], G.shape[1]
         rl, p, rr = core.shape
         two_stage = TWO_STAGE_MIN_P <= p <= TWO_STAGE_MAX_P      # many features: contract them first
+        if two_stage and ca * cb > 1 and G.is_contiguous() and Lk.is_contiguous() \
+                and ca * cb * d.S * rl * rr * 8 <= BOND_LEFT_MAX_BYTES:
+            # all terms of a convolution bond at once: one row GEMM over the stacked features, then the sum over the
+            # left channels inside one kernel
+            T = ops.gemm_rows(G.reshape(ca * cb * d.S, p), core, rl * rr, bmode=1, rl=rl, rr=rr, mm32=self.mm32)
+            out = ops.lcontract_sum(Lk, T.reshape(ca, cb, d.S, rl, rr))
+            if out is not None:
+                return out
         outs = []
         for b in range(cb):
             o = None

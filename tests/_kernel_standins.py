@@ -155,6 +155,10 @@ def lcontract(L, T, out=None):
     return r if out is None else out.add_(r)
 
 
+def lcontract_sum(L, T):
+    return torch.einsum('ascl,absln->bscn', L, T).contiguous()
+
+
 def lcontract_into(L, T, J, a):
     J[:, :, a, :] = torch.einsum('scl,sln->scn', L, T)
     return J
@@ -373,7 +377,7 @@ def lanczos_finish(V, alphas, betas, stop, m_run, x0):
 
 
 NAMES = ("gram_supported env_step_left env_step_right predict loss batch_mean kr_rows hess_left gram gram_scale gram_expand rhs jvp "
-         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec bond_z_supported bond_z patch_contract_multi lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
+         "conv_feature gemm_rows lcontract env_step_left_dense patch_contract gemm_tn chol_solve_dense matvec_fused_supported matvec solve_rhs chol_solve_gram qr dot axpy cg_update lanczos_update lanczos_finish minres_update gl rows_dot rows_matvec_supported rows_matvec rows_rhs lhl rhs_supported rhs_feature bond_supported bond_jv bond_rhs bond_matvec bond_z_supported bond_z lcontract_sum patch_contract_multi lcontract_into filter_supported filter_jv filter_rhs filter_matvec").split()
 
 
 def install(monkeypatch):

@@ -1035,3 +1035,23 @@ def test_lanczos_blocks_queued_by_one_call_equal_single_iterations(S, rl, p, max
     r0 = b - mv(x0)
     res = b - mv(fused)
     assert abs(float((res * r0).sum())) <= 1e-8 * float(r0.norm()) * float(res.norm() + r0.norm())
+
+
+@gpu
+@pytest.mark.parametrize("S,C,rl,n,ca,nb", [(500, 10, 10, 100, 4, 4), (77, 3, 5, 7, 2, 3), (33, 1, 16, 256, 1, 2)])
+def test_left_step_sum_over_channels_in_one_launch(S, C, rl, n, ca, nb):
+    """out[b] = sum_a L_a . T_ab in one launch against one accumulating contraction per term."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(S + n)
+    L = torch.randn(ca, S, C, rl, dtype=torch.float64, generator=gen).to(dev)
+    T = torch.randn(ca, nb, S, rl, n, dtype=torch.float64, generator=gen).to(dev)
+    out = ops.lcontract_sum(L, T)
+    assert out is not None and tuple(out.shape) == (nb, S, C, n)
+    ref = torch.einsum('ascl,absln->bscn', L, T)
+    assert G.rel_err(out, ref) < 1e-13
+    for b in range(nb):
+        o = None
+        for a in range(ca):
+            o = ops.lcontract(L[a], T[a, b].contiguous()) if o is None else ops.lcontract(L[a], T[a, b].contiguous(), out=o)
+        assert G.rel_err(out[b], o) < 1e-14
