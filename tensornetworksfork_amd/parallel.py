@@ -14,11 +14,14 @@ import torch.distributed as dist
 class Shard:
     """Contiguous row block [lo, hi) of this rank out of S rows (sizes differ by at most one)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        """always_collective: issue every collective even in a group of one rank (where each is the
+        identity), so that one GPU can walk the whole RCCL call path of a sharded sweep."""
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self._alone = self.world == 1 and not always_collective
         self._index = {}   # (device, indices) -> device index tensor: built once, no host-to-device copy per update
 
     def bounds(self, S, rank=None):
@@ -43,32 +46,44 @@ class Shard:
     def allreduce_sum_(self, t):
         """In-place sum over ranks.  RCCL handles device tensors; under gloo (CPU
         rehearsal of the multi-rank path) device tensors are staged through the host."""
-        if self.world == 1:
+        if self._alone:
             return t
         if t.is_cuda and self.backend == "gloo":
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
-        else:
+        elif t.is_contiguous():
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:   # RCCL takes dense tensors only (a permuted core, a view of a workspace)
+            c = t.contiguous()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c)
         return t
 
     def common_pair_classes(self, rep, n, device):
         """Feature-pair classes that hold on EVERY rank: two pairs stay in one class only if every
         rank's own samples put them in one (each rank detects classes on its shard).  rep: this
         rank's class representatives (None = no classes); returns the common ones in the same form."""
-        local = torch.tensor(list(range(n)) if rep is None else [int(v) for v in rep], dtype=torch.int64)
-        if self.world > 1:
+        return self.common_pair_classes_many([rep], n, device)[0]
+
+    def common_pair_classes_many(self, reps, n, device):
+        """common_pair_classes for several feature matrices with `n` pairs each in ONE all-gather (all sites of a
+        data set when the first Gram is asked for: a sweep does not stop at every new site for the exchange)."""
+        local = torch.tensor([list(range(n)) if rep is None else [int(v) for v in rep] for rep in reps], dtype=torch.int64)
+        if not self._alone:
             t = local if self.backend == "gloo" else local.to(device)
             parts = [torch.empty_like(t) for _ in range(self.world)]
             dist.all_gather(parts, t, group=self.group)
-            keys = list(zip(*[q.tolist() for q in parts]))
+            parts = [q.tolist() for q in parts]
         else:
-            keys = [(v,) for v in local.tolist()]
-        first, out = {}, []
-        for b, k in enumerate(keys):
-            out.append(first.setdefault(k, b))
-        return None if out == list(range(n)) else out
+            parts = [local.tolist()]
+        out = []
+        for m in range(len(reps)):
+            first, common = {}, []
+            for b, k in enumerate(zip(*[q[m] for q in parts])):
+                common.append(first.setdefault(k, b))
+            out.append(None if common == list(range(n)) else common)
+        return out
 
     def allreduce_gram_(self, ws, b=None):
         """Sum of the compressed Gram (and, in the same message, of the right-hand side `b`) over
@@ -80,7 +95,7 @@ class Shard:
         right behind the Gram (a workspace without such a tail is copied into a fresh message)."""
         G = ws.compressed
         rep = getattr(ws, "pair_rep", None)
-        if self.world == 1:
+        if self._alone:
             return G
         nb = 0 if b is None else b.numel()
         if rep is None:
@@ -121,19 +136,23 @@ class Shard:
 
     def broadcast_(self, t, src=0):
         """Rank `src`'s values on every rank (start vectors drawn from a random generator)."""
-        if self.world == 1:
+        if self._alone:
             return t
         if t.is_cuda and self.backend == "gloo":
             h = t.cpu()
             dist.broadcast(h, src=src, group=self.group)
             t.copy_(h)
-        else:
+        elif t.is_contiguous():
             dist.broadcast(t, src=src, group=self.group)
+        else:
+            c = t.contiguous()
+            dist.broadcast(c, src=src, group=self.group)
+            t.copy_(c)
         return t
 
     def all_true(self, flag, device):
         """Logical AND of a host flag over the ranks (one tiny all-reduce)."""
-        if self.world == 1:
+        if self._alone:
             return bool(flag)
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if self.backend == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)

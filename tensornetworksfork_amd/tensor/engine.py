@@ -431,8 +431,15 @@ class EngineBase:
         if shard is not None:
             rep = self._pair_lookup(X, "common")
             if rep is _MISSING:
-                rep = shard.common_pair_classes(self.pair_rep(X), X.shape[1] * (X.shape[1] + 1) // 2, X.device)
-                self._pair_store(X, "common", rep)
+                # with the feature matrices of the other sites (the same list in the same order on every rank)
+                todo = [X] + [P for P in getattr(lp, "pair_peers", ()) if P.shape == X.shape
+                              and self._pair_key(P, "common")[1] != self._pair_key(X, "common")[1]
+                              and self._pair_lookup(P, "common") is _MISSING]
+                reps = shard.common_pair_classes_many([self.pair_rep(P) for P in todo],
+                                                      X.shape[1] * (X.shape[1] + 1) // 2, X.device)
+                for P, r in zip(todo, reps):
+                    self._pair_store(P, "common", r)
+                rep = reps[0]
         ws = ops.gram(L, H, X, R, sym=sym, ws=ws, pair_rep=rep)
         self._gram_ws[key] = ws
         return ws
@@ -887,10 +894,12 @@ class ChainEngine(EngineBase):
                     hint = getattr(d.xs[j], "ttk_pair_rep", None) if c.kind == "plain" else None
                     if hint is not None and hint[1] == d.xs[j]._version:
                         self._pair_store(self.feats(d, j)[0, 0], "own", list(hint[0]))
-                self.prefetch_pairs([self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"])
+                d.pair_feats = [self.feats(d, j)[0, 0] for j, c in enumerate(self.cols) if c.kind == "plain"]
+                self.prefetch_pairs(d.pair_feats)
             terms = [(L[a], G[a, b], R[b]) for a in range(G.shape[0]) for b in range(G.shape[1])]
             prob = LocalProblem(S, C, (col.rl, col.p, col.rr), core, back, terms=terms)
             prob.mm32 = self.mm32
+            prob.pair_peers = getattr(d, "pair_feats", ())
             if len(terms) > 1 and ops.bond_supported(L, G, R):
                 prob.bond = (L, G, R)
             return prob

@@ -6,6 +6,9 @@ mode "cpu_engine": the package's host logic over the torch stand-ins of the kern
             (tests/_kernel_standins.py) on CPU tensors: sharded conv / CPD / sum-of-networks sweeps.
 mode "gpu": the real engine, every rank on cuda:0 under gloo (device tensors staged through
             the host); a sharded sweep must reproduce the single-process sweep.
+mode "rccl": the cases of "gpu" in a group of ONE rank under the nccl backend (RCCL) with every
+            collective issued all the same: device tensors go to RCCL on the sweep's own streams, as
+            they do with one rank per GPU (two ranks cannot share a GPU under RCCL).
 """
 import os
 import sys
@@ -115,11 +118,15 @@ def _more_gpu_cases(sh, dev):
 
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
+    if mode == "rccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     from tensornetworksfork_amd.parallel import Shard
     from oracle import tt_oracle as O
     torch.set_default_dtype(torch.float64)
-    sh = Shard()
+    sh = Shard(always_collective=mode == "rccl")
     ok = True
     if mode == "cpu":
         S, C, rl, p, rr, bs = 203, 2, 3, 4, 5, 32
@@ -148,6 +155,8 @@ def main():
         ok &= sh.common_pair_classes([0, 0, 0, 3] if sh.rank == 0 else [0, 0, 2, 3], 4, "cpu") == [0, 0, 2, 3]
         ok &= sh.common_pair_classes([0, 1, 1, 3] if sh.rank == 0 else None, 4, "cpu") is None
         ok &= sh.common_pair_classes([0, 1, 1, 1], 4, "cpu") == [0, 1, 1, 1]
+        ok &= sh.common_pair_classes_many([[0, 0, 0, 3] if sh.rank == 0 else [0, 0, 2, 3], None, [0, 1, 1, 1]], 4,
+                                          "cpu") == [[0, 0, 2, 3], None, [0, 1, 1, 1]]
 
         class FakeWS:
             mppad, pair_rep = 6, [0, 1, 1, 3, 0]
@@ -249,7 +258,7 @@ def main():
                 sh.broadcast_(ref)
                 ok &= bool(torch.equal(ref, t))
         ok &= _more_gpu_cases(sh, dev)
-    flag = torch.tensor([1.0 if ok else 0.0])
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda:0" if mode == "rccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if sh.rank == 0:
         with open(out_path, "w") as f:
