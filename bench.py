@@ -270,7 +270,7 @@ def conv_lanczos_variant(device, S, patches, pixels, bond, dtype, conv_bond, tol
     if shard:   # every rank builds the same problem from the same seeds and works on its own block of samples
         import torch.distributed as dist
         world = dist.get_world_size()
-        tn.distribute("auto")
+        tn.distribute(shard if shard is not True else "auto")
         parity = None
     else:
         parity = _conv_identities(tn, x, y, bf)
@@ -462,8 +462,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.set_default_dtype(torch.float64)
-    # rehearsal on a one-GPU box: TTK_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges through gloo
+    # rehearsals on a one-GPU box: TTK_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges through gloo;
+    # TTK_BENCH_REHEARSE=rccl (one rank) takes the multi-rank path through RCCL with every collective issued
     rehearse = os.environ.get("TTK_BENCH_REHEARSE") == "1"
+    rccl_one = os.environ.get("TTK_BENCH_REHEARSE") == "rccl" and world == 1
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -474,14 +476,24 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+    elif rccl_one:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    sharded = world > 1 or rccl_one
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from tensornetworksfork_amd import ops
     F, y, F_val, y_val = synthetic_problem(device)
     layer = make_model(device)
     tn = layer.tensor_network
-    if world > 1:
-        tn.distribute("auto")
+    shard = "auto"
+    if rccl_one:
+        from tensornetworksfork_amd.parallel import Shard
+        shard = Shard(always_collective=True)
+    if sharded:
+        tn.distribute(shard)
     S_train = F[0].shape[0]
 
     def fence():
@@ -502,12 +514,17 @@ def main():
     gram_ms = ops.gram_timing_read()
     ops.gram_timing(False)
     marks, tn._marks = tn._marks, None
-    phase = {"gram_ms": 0.0, "comm_ms": 0.0, "solve_ms": 0.0}
+    # The sweep queues the next node's Gram ahead; the one queued behind the last timed update is called off when the
+    # step counter ends the sweep (most of its workgroups leave at once).  That launch belongs to no update: the
+    # phase sums and the kernel average below take the first `steps` launches, the wall clock covers everything.
+    spans = {"gram_ms": [], "comm_ms": [], "solve_ms": []}
     for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
         key = {("front", "gram"): "gram_ms", ("gram", "comm"): "comm_ms", ("pre", "solve"): "solve_ms"}.get((n0, n1))
         if key:
-            phase[key] += e0.elapsed_time(e1)
-    phase = {k: v / args.steps for k, v in phase.items()}
+            spans[key].append(e0.elapsed_time(e1))
+    phase = {k: sum(v[:args.steps]) / args.steps for k, v in spans.items()}
+    called_off = len(gram_ms) - args.steps
+    gram_ms = gram_ms[:args.steps]
     if dist is not None:
         tmax = torch.tensor([elapsed], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -549,20 +566,20 @@ def main():
                    "batch_size": 512, "sharding": f"samples/{world}", "val_rmse": val_rmse},
         "roofline": {"kernel": "gram_kernel<true>", "bound": "mfma", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "launches": len(gram_ms), "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "launches": len(gram_ms), "launches_called_off": called_off, "avg_launch_ms": avg_ms,
                      "flops_per_launch": gram_flops, "feature_pair_classes": NX,
                      "dense_equivalent_tflops": 2.0 * S_local * D * D / (avg_ms * 1e-3) * 1e-12},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and not sharded:
         probe = dgemm_probe(device)
         probe["gram_frac_of_dgemm"] = achieved / probe["tflops"]
         out["roofline"]["dgemm_probe"] = probe
-    if rank == 0 and world == 1 and not args.no_variants:
+    if rank == 0 and not sharded and not args.no_variants:
         sweep = sweep_variant(device, F, y, F_val, y_val)
         out["sweep_updates_per_sec"] = sweep["core_updates_per_sec"]     # whole first swipe of fit(): 31 updates, edge sites incl.
         out["variants"] = {"cg": cg_variant(device, F, y, steps=10), "sweep": sweep,
                            "lanczos": lanczos_variant(device, F, y)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         out["parity"], out["cpu_baseline"] = parity_and_cpu_baseline(device, F, y)
     if not args.no_variants:
         # image-shaped conv tensor trains: on one GPU the three variants; with N > 1 every rank takes its sample
@@ -571,7 +588,7 @@ def main():
         torch.cuda.empty_cache()
         f64, f32 = torch.float64, torch.float32
         v = out.setdefault("variants", {})
-        if world == 1:
+        if not sharded:
             v["mnist_lanczos"] = conv_lanczos_variant(
                 device, 54000, 50, 17, 24, f64, -1, 1e-9,
                 what="cfg4 shape: 3 carriages, bond 24, 50 patches x 17 pixels, 9 logits, 54000 samples, fp64 "
@@ -580,7 +597,7 @@ def main():
                 device, 54000, 50, 17, 10, f64, 4, 1e-9,
                 what="the MNIST script's own model: bond 10, convolution bond 4 (image_convolution_lanczos_MNIST.py:76)")
         v["cifar_lanczos_f32"] = conv_lanczos_variant(
-            device, 50000, 65, 49, 48, f32, -1, 2e-5, shard=world > 1,
+            device, 50000, 65, 49, 48, f32, -1, 2e-5, shard=shard if rccl_one else sharded,
             what="cfg5 shape: 3 carriages, bond 48, 65 patches x 49 pixels, 9 logits, 50000 samples, float32 nodes and "
                  f"data (CIFAR_lanczos_swipe.py:35-38,68-108); samples sharded over {world} rank(s)")
     if rank == 0:

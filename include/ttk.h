@@ -94,6 +94,17 @@ int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left)
 int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R,
                  int64_t S, int C, int rl, int p, int rr, int sym_left, const int* x_pair_rep,
                  void* ws, int64_t ws_bytes, void* stream);
+/* ttk_gram_f64 that can be called off while it runs.  A sweep queues the next node's Gram before the host knows
+ * whether the sweep goes on (convergence_criterion / timeout / a singular system end it:
+ * tensor/network.py:435-437,482-484,497-504); when it does not, ttk_gram_cancel writes `generation` into the device word
+ * `cancel_word` (4 bytes, on a stream that is not queued behind the Gram) and every workgroup of a
+ * ttk_gram_cancellable_f64 launched with that word and that generation that has not started yet leaves at once:
+ * the workspace then holds nothing of use.  Each launch that shares a word takes a generation of its own, so that no
+ * reset of the word is needed.  cancel_word == NULL: ttk_gram_f64. */
+int ttk_gram_cancellable_f64(const double* L, const double* H, const double* X, const double* R,
+                             int64_t S, int C, int rl, int p, int rr, int sym_left, const int* x_pair_rep,
+                             void* ws, int64_t ws_bytes, const void* cancel_word, unsigned generation, void* stream);
+int ttk_gram_cancel(void* cancel_word, unsigned generation, void* stream);
 int ttk_gram_scale_f64(const void* ws, int rl, int p, int rr, int sym_left, double* scale, void* stream);
 int ttk_gram_expand_f64(const void* ws, int rl, int p, int rr, int sym_left, const double* scale,
                         double ridge, double* A_out, void* stream);

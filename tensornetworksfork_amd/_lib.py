@@ -30,6 +30,9 @@ SIGNATURES = {
     "ttk_hess_left_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),
     "ttk_gram_ws_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
     "ttk_gram_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp, _c_dp, _i64, _c_dp]),
+    "ttk_gram_cancellable_f64": (_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _int, _int, _int, _int, _int, _c_dp, _c_dp, _i64,
+                                        _c_dp, ctypes.c_uint, _c_dp]),
+    "ttk_gram_cancel": (_int, [_c_dp, ctypes.c_uint, _c_dp]),
     "ttk_gram_scale_f64": (_int, [_c_dp, _int, _int, _int, _int, _c_dp, _c_dp]),
     "ttk_gram_expand_f64": (_int, [_c_dp, _int, _int, _int, _int, _c_dp, _dbl, _c_dp, _c_dp]),
     "ttk_gram_timing": (_int, [_int]),

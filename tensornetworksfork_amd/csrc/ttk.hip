@@ -983,8 +983,12 @@ __device__ __forceinline__ void gram_steps(const double* __restrict__ smem, int 
 
 template <bool C1>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ F, int64_t S, int C, int rl, int p,
-                                                       int rr, int sym, GramDims gd, double* __restrict__ partial) {
+                                                       int rr, int sym, GramDims gd, double* __restrict__ partial,
+                                                       const unsigned* __restrict__ cancel, unsigned generation) {
   extern __shared__ double smem[];
+  // a caller that has no use for this Gram any more writes its generation into the cancel word: workgroups that
+  // start after that leave at once (the load is issued here and looked at after the index set-up below)
+  const unsigned cancelled = cancel ? __hip_atomic_load(cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const int CW = C * rl;
   const int CH = gd.CH;
   const int W = 2 * CW + gd.NX + rr + 1;
@@ -1047,6 +1051,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   if (s_end > S) s_end = S;
   const int bufd = gd.bufd;   // doubles per LDS buffer
   int cur = 0;
+  if (cancel && cancelled == generation) return;   // uniform over the workgroup
   if (s_begin < s_end)
     gram_chunk_copy(F + s_begin * W, (((int)min((int64_t)CH, s_end - s_begin) + 3) & ~3) * W, smem, wave, lane);
   for (int64_t c0 = s_begin; c0 < s_end; c0 += CH) {
@@ -4564,6 +4569,18 @@ int64_t ttk_gram_ws_bytes(int64_t S, int C, int rl, int p, int rr, int sym_left)
 
 int ttk_gram_f64(const double* L, const double* H, const double* X, const double* R, int64_t S, int C, int rl, int p,
                  int rr, int sym_left, const int* x_pair_rep, void* ws, int64_t ws_bytes, void* stream) {
+  return ttk_gram_cancellable_f64(L, H, X, R, S, C, rl, p, rr, sym_left, x_pair_rep, ws, ws_bytes, nullptr, 0u, stream);
+}
+
+int ttk_gram_cancel(void* cancel_word, unsigned generation, void* stream) {
+  if (!cancel_word) return TTK_EINVAL;
+  if (hipMemsetD32Async((hipDeviceptr_t)cancel_word, (int)generation, 1, (hipStream_t)stream) != hipSuccess) return TTK_ELAUNCH;
+  return TTK_OK;
+}
+
+int ttk_gram_cancellable_f64(const double* L, const double* H, const double* X, const double* R, int64_t S, int C, int rl,
+                             int p, int rr, int sym_left, const int* x_pair_rep, void* ws, int64_t ws_bytes,
+                             const void* cancel_word, unsigned generation, void* stream) {
   if (!L || !H || !X || !R || !ws || S < 1 || C < 1 || rl < 1 || p < 1 || rr < 1) return TTK_EINVAL;
   const int NX = p * (p + 1) / 2;
   int nrep = 0;
@@ -4599,10 +4616,10 @@ int ttk_gram_f64(const double* L, const double* H, const double* X, const double
   if (timed) (void)hipEventRecord(g_ev_start[g_ev_count], st);
   if (C == 1)
     hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds, st, (const double*)F, S, C, rl, p, rr, sym_left,
-                       d, partial);
+                       d, partial, (const unsigned*)cancel_word, generation);
   else
     hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds, st, (const double*)F, S, C, rl, p, rr, sym_left,
-                       d, partial);
+                       d, partial, (const unsigned*)cancel_word, generation);
   if (timed) (void)hipEventRecord(g_ev_stop[g_ev_count++], st);
   int rc = ttk_launch_status();
   if (rc != TTK_OK) return rc;

@@ -189,6 +189,7 @@ class GramWorkspace:
         self.mppad = (mp + 47) // 48 * 48    # leading extent of the compressed Gram [mppad][pairs(p,q)][nrpad]
         self.pair_rep = None                 # feature-pair classes of the last Gram computed into it
         self.generation = 0                  # bumped by every Gram computed into this workspace
+        self.cancel_word = torch.zeros(1, dtype=torch.int32, device=device)   # see gram_cancel
 
     @property
     def compressed(self):
@@ -208,13 +209,22 @@ def gram(L, H, X, R, sym=True, ws=None, pair_rep=None):
         if len(pair_rep) != p * (p + 1) // 2:
             raise _lib.TTKError("pair_rep: expected one entry per feature pair")
         rep = (ctypes.c_int * len(pair_rep))(*[int(v) for v in pair_rep])
-    rc = _lib.lib().ttk_gram_f64(_chk(L, "L"), _chk(H, "H", (S, C, C)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)),
-                                 S, C, rl, p, rr, int(bool(sym)), None if rep is None else ctypes.cast(rep, ctypes.c_void_p),
-                                 ws.buf.data_ptr(), ws.nbytes, _stream(L))
-    _lib.check(rc, "ttk_gram_f64")
+    ws.generation += 1                       # (the kernel is told generation % (2^32 - 1) + 1: never the word's initial 0)
+    rc = _lib.lib().ttk_gram_cancellable_f64(
+        _chk(L, "L"), _chk(H, "H", (S, C, C)), _chk(X, "X", (S, p)), _chk(R, "R", (S, rr)), S, C, rl, p, rr, int(bool(sym)),
+        None if rep is None else ctypes.cast(rep, ctypes.c_void_p), ws.buf.data_ptr(), ws.nbytes, ws.cancel_word.data_ptr(),
+        ws.generation % 0xFFFFFFFF + 1, _stream(L))
+    _lib.check(rc, "ttk_gram_cancellable_f64")
     ws.pair_rep = None if pair_rep is None else [int(v) for v in pair_rep]
-    ws.generation += 1
     return ws
+
+
+def gram_cancel(ws):
+    """Call off the last Gram queued into `ws` (ops.gram): workgroups of its kernel that have not started yet leave at
+    once and the workspace holds nothing of use afterwards.  Queued on the CURRENT stream, which must not be waiting
+    for the stream the Gram runs on, or the word arrives after the kernel."""
+    rc = _lib.lib().ttk_gram_cancel(ws.cancel_word.data_ptr(), ws.generation % 0xFFFFFFFF + 1, _stream(ws.cancel_word))
+    _lib.check(rc, "ttk_gram_cancel")
 
 
 def gram_scale(ws):

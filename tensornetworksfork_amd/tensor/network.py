@@ -682,6 +682,13 @@ class TensorNetwork:
             with torch.cuda.stream(pipe):
                 return swipes()
         finally:
+            # a Gram queued ahead for a node the sweep never came to (it converged, timed out, ...) is called off: the
+            # caller's stream is not queued behind it
+            spec, self._spec = self._spec, None
+            ws = spec[1].get("ws") if spec is not None else None
+            if ws is not None and spec[1]["gen"] == ws.generation:
+                with torch.cuda.stream(user):
+                    ops.gram_cancel(ws)
             self._streams = self._nodes_ready = self._sweep_d = None
             user.wait_stream(pipe)
 

@@ -237,6 +237,28 @@ def test_gram_large_slabbed():
 
 
 @gpu
+def test_gram_called_off():
+    """A Gram whose generation stands in the cancel word does no work (every workgroup leaves: the workspace keeps
+    what the slab sums of its old contents give); the next one, a generation later, is complete again, bit for bit."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    S, C, rl, p, rr = 20000, 1, 8, 6, 8
+    L, X, R = _rand((S, C, rl), 31).to(dev), _rand((S, p), 32).to(dev), _rand((S, rr), 33).to(dev)
+    H = torch.full((S, 1, 1), 2.0, dtype=torch.float64, device=dev)
+    ws = ops.gram(L, H, X, R, sym=True)
+    want = ws.compressed.clone()
+    assert want.abs().max().item() > 0
+    ws.buf.zero_()
+    ws.cancel_word.fill_(ws.generation % 0xFFFFFFFF + 2)      # the generation the next call will carry
+    ws2 = ops.gram(L, H, X, R, sym=True, ws=ws)
+    assert ws2 is ws and ws.compressed.abs().max().item() == 0.0
+    ops.gram_cancel(ws)                                        # what a sweep does: same word, same generation
+    assert int(ws.cancel_word.item()) == ws.generation % 0xFFFFFFFF + 1
+    ops.gram(L, H, X, R, sym=True, ws=ws)
+    assert torch.equal(ws.compressed, want)
+
+
+@gpu
 @pytest.mark.parametrize("S,C,rl,p,rr", [(96, 1, 4, 3, 4), (400, 1, 8, 3, 8), (700, 2, 7, 5, 9), (900, 1, 16, 6, 16),
                                          (64, 1, 4, 3, 1), (50, 1, 1, 5, 4)])
 def test_cholesky_solve(S, C, rl, p, rr):
