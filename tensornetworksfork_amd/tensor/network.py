@@ -126,7 +126,10 @@ class TensorNetwork:
         user = torch.cuda.current_stream(device)
         pipe = TensorNetwork._pipe_streams.get(device)
         if pipe is None:
-            pipe = TensorNetwork._pipe_streams[device] = torch.cuda.Stream(device)
+            # High priority: streams of one priority share a few hardware queues in creation order, and behind the
+            # streams a collective library creates the pipeline stream can land on the caller's queue, which runs
+            # the two one after the other (measured on the multi-rank path: 0.3 ms per core update).
+            pipe = TensorNetwork._pipe_streams[device] = torch.cuda.Stream(device, priority=-1)
         return user, pipe
 
     def _user_guard(self, d=None, heavy=False):
