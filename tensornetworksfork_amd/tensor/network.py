@@ -373,17 +373,17 @@ class TensorNetwork:
         g, H = self._norm_gh(grad, hess, d.S, lp.C)
         total = self._host_scalar(self._batch_mean_loss(d, loss, batch_size)) if want_loss else None
         b = lp.rhs(g)
-        front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None, "gen": None}
+        front = {"lp": lp, "total": total, "b": b, "ws": None, "A_f": None, "gen": None, "mark": self._mark_pick()}
         # (the closed-form losses are symmetric by construction: no host read, no collective for them)
         sym = closed_form_symmetric_hessian(loss_fn) or self._hessian_symmetric(H, sharded=d.sharded)
         if lp.compressed_gram(sym):
             # compressed symmetric Gram in the workspace, own Cholesky on it
-            self._mark("front")
+            self._mark("front", front["mark"])
             ws = self._engine.gram_ws(lp, H, sym, shard=self._shard if d.sharded else None)
-            self._mark("gram")
+            self._mark("gram", front["mark"])
             if d.sharded:   # one all-reduce of [compressed Gram | RHS] per core update
                 self._shard.allreduce_gram_(ws, b)
-                self._mark("comm")
+                self._mark("comm", front["mark"])
             front["ws"] = ws
             front["gen"] = ws.generation   # the workspace is shared: a later Gram into it outdates this front
         else:
@@ -433,9 +433,9 @@ class TensorNetwork:
         if front["ws"] is not None:
             ws = front["ws"]
             scale = ops.gram_scale(ws)
-            self._mark("pre")
+            self._mark("pre", front["mark"])
             x, info = ops.chol_solve_gram(ws, b, core if ridged else None, scale, ridge)
-            self._mark("solve")
+            self._mark("solve", front["mark"])
             if not lu:
                 self._pend_pivot_check(info, node)
             elif int(info.item()) != 0:
@@ -473,14 +473,21 @@ class TensorNetwork:
         ready.record()
         return (host, ready)
 
-    def _mark(self, name):
-        """Phase marks for benchmarking: with `self._marks` set to a list, a device event is recorded
-        at the end of each phase of a core update (no effect, no cost otherwise)."""
-        marks = getattr(self, "_marks", None)
-        if marks is not None:
+    def _mark_pick(self):
+        """Phase marks for benchmarking: with `self._marks` set to a list, device events are recorded at the phase
+        boundaries of every `self._mark_every`-th core update (an event costs about as much as a small kernel; no
+        effect, no cost otherwise).  Returns the index of the update whose front is being queued if it is one of
+        those, else None."""
+        if getattr(self, "_marks", None) is None:
+            return None
+        k = self._mark_count = getattr(self, "_mark_count", -1) + 1
+        return k if k % max(1, getattr(self, "_mark_every", 1)) == 0 else None
+
+    def _mark(self, name, index):
+        if index is not None and getattr(self, "_marks", None) is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            marks.append((name, ev))
+            self._marks.append((name, ev, index))
 
     def _pend_pivot_check(self, info, node):
         """The pivot check of a Cholesky needs the host; it is settled after the gauge move has been
