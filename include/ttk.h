@@ -218,6 +218,14 @@ int ttk_chol_mode(int mode);
 int64_t ttk_qr_lds_bytes(int m, int n);
 int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream);
 
+/* The gauge move to the left of node_orthonormalize_right (tensor/network.py:672-704) in one launch: the core as it
+ * lies in memory, T (n, m) row-major with the left bond n first, is factorised as T = Rm Qt, Qt (k, m) with orthonormal
+ * rows (the new core), Rm (n, k) (what the previous core is multiplied with, network.py:704), k = min(m, n) - the
+ * reference's QR of the doubly flipped transposed matrix (network.py:685-689, same reflectors in the same order, same
+ * signs) read and written through index maps instead of permute / flip / transpose copies.  Same size limit as ttk_qr_f64
+ * with (m, n). */
+int ttk_qr_right_f64(const double* T, int n, int m, double* Qt, double* Rm, void* stream);
+
 /* Krylov vector kernels with wavefront-shuffle reductions (lanczos_solver,
  * tensor/network.py:796-824): out[0] = <x,y>;  y += a[0]*x  (a on device);
  * Both leave results on the device so that an iteration needs no host sync. */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ttk_chol_mode": (_int, [_int]),
     "ttk_qr_lds_bytes": (_i64, [_int, _int]),
     "ttk_qr_f64": (_int, [_c_dp, _int, _int, _c_dp, _c_dp, _c_dp]),
+    "ttk_qr_right_f64": (_int, [_c_dp, _int, _int, _c_dp, _c_dp, _c_dp]),
     "ttk_dot_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_axpy_f64": (_int, [_c_dp, _dbl, _c_dp, _c_dp, _i64, _c_dp]),
     "ttk_gl_f64": (_int, [_c_dp, _c_dp, _c_dp, _i64, _int, _int, _c_dp]),

@@ -4170,10 +4170,18 @@ __device__ __forceinline__ void qr_wave_sum8(double (&acc)[8], int lane) {
   for (int q = 0; q < 8; ++q) acc[q] = qr_readlane(one, ((q >> 2) & 1) * 32 + ((q >> 1) & 1) * 16 + (q & 1) * 8);
 }
 
+// Where the QR kernels find element (r, c) of the matrix they factorise and put those of Q (m x k) and R (k x n):
+// offset + r * row stride + c * column stride, strides of either sign.  A gauge move to the left is the QR of the
+// doubly flipped transposed core (tensor/network.py:686-690): with these maps it reads the core as it lies in memory
+// and writes the new core and the bond factor as they are used, no flip or transposition kernels around it.
+struct QrMap {
+  int64_t a_off, a_sr, a_sc, q_off, q_sr, q_sc, r_off, r_sr, r_sc;
+};
+
 #define QRS_RPL 4
 #define QRS_CPW 8
 __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict__ Ain, int m, int n,
-                                                        double* __restrict__ Q, double* __restrict__ Rout) {
+                                                        double* __restrict__ Q, double* __restrict__ Rout, QrMap mp) {
   __shared__ double V[32][256];      // reflector j: V[j][row], zero above j, one at j
   __shared__ double tau[32];
   const int k = min(m, n);
@@ -4184,7 +4192,7 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
 #pragma unroll
     for (int e = 0; e < QRS_RPL; ++e) {
       const int c = wave + 4 * q, r = lane + 64 * e;
-      const double v = Ain[(int64_t)min(r, m - 1) * n + min(c, n - 1)];
+      const double v = Ain[mp.a_off + (int64_t)min(r, m - 1) * mp.a_sr + (int64_t)min(c, n - 1) * mp.a_sc];
       a[q][e] = (r < m && c < n) ? v : 0.0;
     }
   for (int j = 0; j < k; ++j) {
@@ -4258,7 +4266,7 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
 #pragma unroll
     for (int e = 0; e < QRS_RPL; ++e) {
       const int c = wave + 4 * q, r = lane + 64 * e;
-      if (r < k && c < n) Rout[(int64_t)r * n + c] = (r <= c) ? a[q][e] : 0.0;
+      if (r < k && c < n) Rout[mp.r_off + (int64_t)r * mp.r_sr + (int64_t)c * mp.r_sc] = (r <= c) ? a[q][e] : 0.0;
     }
   __syncthreads();   // every reflector is in V
   // Q = H_1 ... H_k I[:, :k], own columns, last reflector first; H_j leaves unit columns left of j alone
@@ -4295,12 +4303,12 @@ __global__ __launch_bounds__(256) void qr_small_kernel(const double* __restrict_
 #pragma unroll
     for (int e = 0; e < QRS_RPL; ++e) {
       const int c = wave + 4 * q, r = lane + 64 * e;
-      if (r < m && c < k) Q[(int64_t)r * k + c] = a[q][e];
+      if (r < m && c < k) Q[mp.q_off + (int64_t)r * mp.q_sr + (int64_t)c * mp.q_sc] = a[q][e];
     }
 }
 
 __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain, int m, int n, double* __restrict__ Q,
-                                                  double* __restrict__ Rout) {
+                                                  double* __restrict__ Rout, QrMap mp) {
   extern __shared__ double smem[];
   const int k = min(m, n);
   const int ldm = m + 1;
@@ -4308,9 +4316,17 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   double* tau = A + (size_t)n * ldm;
   double* Qw = tau + k + 8 + n;     // Qw[c * ldm + r], m x k
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool rows_fast = mp.a_sr == 1 || mp.a_sr == -1;   // consecutive threads along whichever index is dense in memory
   for (int idx = tid; idx < m * n; idx += 256) {
-    const int r = idx / n, c = idx - r * n;
-    A[c * ldm + r] = Ain[idx];
+    int r, c;
+    if (rows_fast) {
+      c = idx / m;
+      r = idx - c * m;
+    } else {
+      r = idx / n;
+      c = idx - r * n;
+    }
+    A[c * ldm + r] = Ain[mp.a_off + (int64_t)r * mp.a_sr + (int64_t)c * mp.a_sc];
   }
   __syncthreads();
   // Columns are dealt to the four waves (c mod 4).  The owner of column j forms its reflector
@@ -4371,7 +4387,7 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   // R (k x n, upper triangular)
   for (int idx = tid; idx < k * n; idx += 256) {
     const int r = idx / n, c = idx - r * n;
-    Rout[idx] = (r <= c) ? A[c * ldm + r] : 0.0;
+    Rout[mp.r_off + (int64_t)r * mp.r_sr + (int64_t)c * mp.r_sc] = (r <= c) ? A[c * ldm + r] : 0.0;
   }
   // Q = H_1 ... H_k I[:, :k] (dorg2r).  Column c of the identity is touched by H_j only for
   // j <= c, and the columns are independent: each wave runs its own columns through their
@@ -4418,8 +4434,15 @@ __global__ __launch_bounds__(256) void qr_kernel(const double* __restrict__ Ain,
   }
   __syncthreads();
   for (int idx = tid; idx < m * k; idx += 256) {
-    const int r = idx / k, c = idx - r * k;
-    Q[idx] = Qw[c * ldm + r];
+    int r, c;
+    if (rows_fast) {
+      c = idx / m;
+      r = idx - c * m;
+    } else {
+      r = idx / k;
+      c = idx - r * k;
+    }
+    Q[mp.q_off + (int64_t)r * mp.q_sr + (int64_t)c * mp.q_sc] = Qw[c * ldm + r];
   }
 }
 
@@ -5056,10 +5079,9 @@ int64_t ttk_qr_lds_bytes(int m, int n) {
   return ((int64_t)n * (m + 1) + k + 8 + n + k * (int64_t)(m + 1)) * (int64_t)sizeof(double);
 }
 
-int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream) {
-  if (!A || !Q || !R || m < 1 || n < 1) return TTK_EINVAL;
+static int qr_launch(const double* A, int m, int n, double* Q, double* R, const QrMap& mp, hipStream_t st) {
   if (m <= 64 * QRS_RPL && n <= 4 * QRS_CPW) {
-    hipLaunchKernelGGL(qr_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, m, n, Q, R);
+    hipLaunchKernelGGL(qr_small_kernel, dim3(1), dim3(256), 0, st, A, m, n, Q, R, mp);
     return ttk_launch_status();
   }
   const int64_t lds = ttk_qr_lds_bytes(m, n);
@@ -5067,8 +5089,23 @@ int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TTK_ELAUNCH;
-  hipLaunchKernelGGL(qr_kernel, dim3(1), dim3(256), (size_t)lds, (hipStream_t)stream, A, m, n, Q, R);
+  hipLaunchKernelGGL(qr_kernel, dim3(1), dim3(256), (size_t)lds, st, A, m, n, Q, R, mp);
   return ttk_launch_status();
+}
+
+int ttk_qr_f64(const double* A, int m, int n, double* Q, double* R, void* stream) {
+  if (!A || !Q || !R || m < 1 || n < 1) return TTK_EINVAL;
+  const int k = m < n ? m : n;
+  const QrMap mp = {0, n, 1, 0, k, 1, 0, n, 1};
+  return qr_launch(A, m, n, Q, R, mp, (hipStream_t)stream);
+}
+
+int ttk_qr_right_f64(const double* T, int n, int m, double* Qt, double* Rm, void* stream) {
+  if (!T || !Qt || !Rm || m < 1 || n < 1) return TTK_EINVAL;
+  const int64_t k = m < n ? m : n, M = m, N = n;
+  // element (r, c) of the flipped transposed core is T[n-1-c][m-1-r]; Q[r][c] goes to Qt[k-1-c][m-1-r], R[r][c] to Rm[n-1-c][k-1-r]
+  const QrMap mp = {(N - 1) * M + (M - 1), -1, -M, (k - 1) * M + (M - 1), -1, -M, (N - 1) * k + (k - 1), -1, -k};
+  return qr_launch(T, m, n, Qt, Rm, mp, (hipStream_t)stream);
 }
 
 int ttk_solve_rhs_f64(const double* b, const double* w, const double* scale, double ridge, double* out, int64_t D,

@@ -512,6 +512,24 @@ def qr(A):
     return Q, R
 
 
+def qr_right_supported(T):
+    """Whether qr_right takes this (n, m) matrix: float64 on the device, contiguous, within the one-workgroup QR."""
+    return T.is_cuda and T.dtype == F64 and T.ndim == 2 and T.is_contiguous() \
+        and _lib.lib().ttk_qr_lds_bytes(T.shape[1], T.shape[0]) <= QR_LDS_LIMIT
+
+
+def qr_right(T):
+    """T (n, m) = Rm Qt with Qt (k, m) of orthonormal rows and Rm (n, k): the QR of the doubly flipped transposed
+    matrix (tensor/network.py:685-689) in one launch, nothing copied around it."""
+    n, m = T.shape
+    k = min(m, n)
+    Qt = torch.empty((k, m), dtype=F64, device=T.device)
+    Rm = torch.empty((n, k), dtype=F64, device=T.device)
+    rc = _lib.lib().ttk_qr_right_f64(T.data_ptr(), n, m, Qt.data_ptr(), Rm.data_ptr(), _stream(T))
+    _lib.check(rc, "ttk_qr_right_f64")
+    return Qt, Rm
+
+
 def dot(x, y):
     out = torch.empty((), dtype=F64, device=x.device)
     rc = _lib.lib().ttk_dot_f64(_chk(x, "x"), _chk(y, "y"), out.data_ptr(), x.numel(), _stream(x))

@@ -764,12 +764,19 @@ class TensorNetwork:
             return
         bond = [node.dim_labels.index(lab) for lab in node.left_labels]
         rest = [a for a in range(node.tensor.ndim) if a not in bond]
-        perm = rest + bond
-        P = node.tensor.permute(perm)
-        Qr, Rr = ops.qr(torch.flip(P.flatten(0, len(rest) - 1), dims=[0, 1]))
-        Rm = torch.flip(Rr.T, dims=[0, 1])
-        Q = torch.flip(Qr, dims=[0, 1]).reshape(tuple(P.shape[:len(rest)]) + (Qr.shape[-1],))
-        node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))
+        T2 = node.tensor.reshape(node.tensor.shape[0], -1) if bond == [0] and node.tensor.is_contiguous() else None
+        if T2 is not None and ops.qr_right_supported(T2):
+            # the left bond is the leading axis of a dense core: one kernel reads it in place and writes the new core
+            # and the bond factor as they are used
+            Qt, Rm = ops.qr_right(T2)
+            node.tensor = Qt.reshape((Qt.shape[0],) + tuple(node.tensor.shape[1:]))
+        else:
+            perm = rest + bond
+            P = node.tensor.permute(perm)
+            Qr, Rr = ops.qr(torch.flip(P.flatten(0, len(rest) - 1), dims=[0, 1]))
+            Rm = torch.flip(Rr.T, dims=[0, 1])
+            Q = torch.flip(Qr, dims=[0, 1]).reshape(tuple(P.shape[:len(rest)]) + (Qr.shape[-1],))
+            node.tensor = Q.permute(*sorted(range(len(perm)), key=lambda a: perm[a]))
         prev = self.main_nodes[i - 1]
         prev.permute_last(*node.get_connecting_labels(prev))
         prev.tensor = self._bond_product(Rm, prev.tensor, first=False)

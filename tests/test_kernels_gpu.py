@@ -522,6 +522,25 @@ def test_qr_matches_lapack(m, n):
 
 
 @gpu
+@pytest.mark.parametrize("n,m", [(32, 192), (16, 96), (6, 24), (10, 500), (8, 5), (1, 7), (24, 300), (64, 64)])
+def test_qr_right_matches_flipped_lapack(n, m):
+    """The gauge move to the left in one launch (core read in place, factors written as they are used) against the
+    reference's construction on the CPU: QR of the doubly flipped transposed matrix, factors flipped back."""
+    from tensornetworksfork_amd import ops
+    dev = _dev()
+    T = _rand((n, m), 52)
+    assert ops.qr_right_supported(T.to(dev))
+    Qt, Rm = ops.qr_right(T.to(dev))
+    Qr, Rr = torch.linalg.qr(torch.flip(T.T, dims=[0, 1]), mode='reduced')
+    Rw = torch.flip(Rr.T, dims=[0, 1])
+    Qw = torch.flip(Qr, dims=[0, 1])
+    assert tuple(Qt.shape) == tuple(Qw.T.shape) and tuple(Rm.shape) == tuple(Rw.shape)
+    assert G.rel_err(Qt, Qw.T) < 1e-10
+    assert G.rel_err(Rm, Rw) < 1e-10
+    assert G.rel_err(Rm.cpu() @ Qt.cpu(), T) < 1e-12
+
+
+@gpu
 def test_gram_feature_pair_classes():
     """Polynomial features: the classed Gram (one slice per value of p+q) equals the full one."""
     from tensornetworksfork_amd import ops
