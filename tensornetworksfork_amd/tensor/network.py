@@ -596,7 +596,7 @@ class TensorNetwork:
                 o = last[other]
                 if node in self.node_indices and o in self.node_indices and self.node_indices[node] == self.node_indices[o]:
                     continue
-                if timeout is not None and (time.time() - start) > timeout:
+                if self._timed_out(d, start, timeout):
                     print(f"Timeout reached ({timeout} seconds). Stopping accumulating_swipe.")
                     return False
                 try:
@@ -803,6 +803,17 @@ class TensorNetwork:
             return lambda v: self._shard.allreduce_sum_(mv(v))
         return mv
 
+    def _timed_out(self, d, start, timeout):
+        """The timeout test of the sweeps (tensor/network.py:435,537,741,865).  Sample-sharded runs agree on it (one
+        tiny all-reduce per node, only when a timeout is set): a rank that left by its own clock would leave the
+        others waiting in the next collective."""
+        if timeout is None:
+            return False
+        out = (time.time() - start) > timeout
+        if d.sharded and self._shard is not None:
+            out = not self._shard.all_true(not out, d.xs[0].device)
+        return out
+
     def _sweep_data(self, x, y_true, batch_size):
         self._require_chain()
         d = self._data_for(x, shard=self._shard)
@@ -823,7 +834,7 @@ class TensorNetwork:
         start = time.time() if timeout is not None else None
         for NS in range(num_swipes):
             for node in (self.train_nodes if NS % 2 == 0 else reversed(self.train_nodes)):
-                if timeout is not None and (time.time() - start) > timeout:
+                if self._timed_out(d, start, timeout):
                     print(f"Timeout reached ({timeout} seconds). Stopping lanczos_swipe.")
                     return False
                 lp, H, b, lossv = self._krylov_setup(d, node, y, loss_fn, batch_size, loss_callback is not None)
@@ -853,7 +864,7 @@ class TensorNetwork:
         kind = _scipy_kind(solver)
         for NS in range(num_swipes):
             for node in (self.train_nodes if NS % 2 == 0 else reversed(self.train_nodes)):
-                if timeout is not None and (time.time() - start) > timeout:
+                if self._timed_out(d, start, timeout):
                     print(f"Timeout reached ({timeout} seconds). Stopping lanczos_swipe.")
                     return False
                 lp, H, b, lossv = self._krylov_setup(d, node, y, loss_fn, batch_size, loss_callback is not None)

@@ -81,11 +81,11 @@ def _more_gpu_cases(sh, dev):
         def run(tn, sweep=sweep, x=x, y=y):
             bf = XEAutogradBregman(w=1.0)
             if sweep == "lanczos":
-                tn.lanczos_swipe(x, y, bf, batch_size=64, num_swipes=1, max_iter=3)
+                tn.lanczos_swipe(x, y, bf, batch_size=64, num_swipes=1, max_iter=3, timeout=1e6)   # (a timeout is agreed on by the ranks)
             elif sweep == "minres":
                 tn.scipy_swipe(x, y, bf, spla.minres, batch_size=64, num_swipes=1, max_iter=4)
             else:
-                tn.accumulating_swipe(x, y, bf, batch_size=64, num_swipes=1, method="ridge_cholesky", eps=0.1)
+                tn.accumulating_swipe(x, y, bf, batch_size=64, num_swipes=1, method="ridge_cholesky", eps=0.1, timeout=1e6)
         compare(make, run, tol, f"conv {dt} cb={cb} {sweep}")
 
     # CPD layer and type-I sums under the Gauss-Newton sweep
