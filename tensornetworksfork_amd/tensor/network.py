@@ -627,7 +627,9 @@ class TensorNetwork:
                             # has been undone: from here on this process factorises with one launch per panel, and the
                             # node is done again.
                             self._spec = None
-                            if attempt or ops.chol_mode(0) == 0:
+                            # (sample-sharded: the abort is this rank's alone and a second attempt would issue collectives
+                            # the other ranks do not: the rank fails instead of leaving them waiting)
+                            if attempt or d.sharded or ops.chol_mode(0) == 0:
                                 raise RuntimeError("ttk_chol_solve_f64: the factorisation was aborted (a workgroup waited "
                                                    "for a tile beyond its limit); the update has been undone") from None
                 except torch.linalg.LinAlgError:
