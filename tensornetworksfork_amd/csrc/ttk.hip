@@ -3253,20 +3253,22 @@ __device__ __forceinline__ void dag_store2(__amdgpu_buffer_rsrc_t r, unsigned of
 __device__ __forceinline__ unsigned dag_wait(unsigned* rowready, unsigned* ctl, int ra, int rb, int rc, unsigned need,
                                              int tid) {
   const unsigned spin_limit = ctl[4];   // written by the host before the launch, constant during it
-  if (tid == 0) {
+  if (tid < 64) {   // the first wave: lanes 0, 1, 2 look at one row each, one round trip per look
     unsigned a = 0, spins = 0;
+    unsigned* mine = rowready + (size_t)(tid == 0 ? ra : (tid == 1 ? rb : rc)) * DAG_SLOT;
     for (;;) {
-      a = min(dag_poll(rowready + (size_t)ra * DAG_SLOT), dag_poll(rowready + (size_t)rb * DAG_SLOT));
-      if (rc != rb) a = min(a, dag_poll(rowready + (size_t)rc * DAG_SLOT));
+      const unsigned v = tid < 3 ? dag_poll(mine) : 0u;
+      a = min(min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 1)),
+              (unsigned)__builtin_amdgcn_readlane((int)v, 2));
       if (a >= need) break;
-      if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {
-        dag_post(ctl + 1, 1u);
+      if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {   // uniform over the wave
+        if (tid == 0) dag_post(ctl + 1, 1u);
         a = 0;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
-    dag_word[2] = a;
+    if (tid == 0) dag_word[2] = a;
   }
   __syncthreads();
   const unsigned seen = dag_word[2];
@@ -4014,20 +4016,19 @@ __global__ __launch_bounds__(256) void chol_back_chain_kernel(double* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) gl[m][e] = Lmk[(int64_t)e * ld];
     }
-    if (threadIdx.x == 0) {   // the rows of the group are final
+    if (g == 0) {   // the rows of the group are final: lane m of the first wave looks at row jlo + m, one round trip per look
       unsigned ok = 1, spins = 0;
       for (;;) {
-        unsigned a = BACK_READY;
-        for (int m = 0; m < ng; ++m) a = min(a, dag_poll(rowready + (size_t)(jlo + m) * DAG_SLOT));
-        if (a >= BACK_READY) break;
-        if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {
-          dag_post(ctl + 1, 1u);
+        const unsigned a = c < ng ? dag_poll(rowready + (size_t)(jlo + c) * DAG_SLOT) : BACK_READY;
+        if (__all(a >= BACK_READY)) break;
+        if ((++spins & 63u) == 0 && (dag_poll(ctl + 1) != 0 || spins > spin_limit)) {   // uniform over the wave
+          if (c == 0) dag_post(ctl + 1, 1u);
           ok = 0;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      seen = ok;
+      if (c == 0) seen = ok;
     }
     __syncthreads();
     if (!seen) {
